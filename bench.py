@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json headline metric: particle-updates/sec (range update + resample) at N = 16 M.
+
+Workload (BASELINE.json configs[2], SURVEY.md 8d "config 3", the roofline case): one particleFilterLoc of
+N = 16 000 000 particles per GPU, 8 beacons at (+-5, +-5, {0.5, 3.0}) m, truth on a 2 m circle moving
+5 cm per step, ranges = true distance + N(0, 0.1^2).  One STEP = depositVio + depositRange(beacon k%8) +
+depositRssi(beacon (k+1)%8): two deposits, i.e. 2N particle-updates (one particle through one
+depositRange/Rssi call: VIO commit, gate, sums, decision, resample-or-normalise).  The first deposit of a
+step carries the VIO motion, the second has zero motion.  Particles live in HBM the whole time; the only
+host->device traffic in the timed region is kernel arguments.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n PARTICLES_PER_GPU] [--force-branch -1|0|1]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): ONE filter of N x 16 M particles sharded by
+particle range; per deposit an all-gather of the per-GPU weight/pose sums (RCCL) gives every rank the
+global decision and its CDF base; see slam3d_amd/sharded.py.  Weak scaling: per-GPU work fixed.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# SURVEY.md 8d / BASELINE.md: algorithmic (compulsory) HBM bytes per particle, SoA f32
+ALG_BYTES = {"stream": 44, "stream_static": 28, "resample": 40}
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def scene(n_steps):
+    import _synth
+    return _synth.synthetic_scene(n_steps, seed=42)
+
+
+def step(pf, k, bx, truth, rng):
+    """one STEP of the workload on any object with the wrapper interface"""
+    pf.depositVio(1000.0 + 0.1 * k, float(truth[k, 0]), float(truth[k, 1]), float(truth[k, 2]), 0.0)
+    b = k % 8
+    pf.depositRange(float(bx[b, 0]), float(bx[b, 1]), float(bx[b, 2]), float(rng[k, 0]), 0.1)
+    b = (k + 1) % 8
+    pf.depositRssi(float(bx[b, 0]), float(bx[b, 1]), float(bx[b, 2]), -60)
+
+
+# ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+class _RefLoc:
+    """The COMPILED REFERENCE (oracle/_ref/libpf_ref_glibc_n1m.so: the reference's own sources built with
+    PF_N_TAG_LOC = 1 000 000) behind the wrapper interface."""
+    N = 1000000
+
+    def __init__(self, path):
+        self.L = C.CDLL(path)
+        f, d = C.c_float, C.c_double
+        self.L.particleFilterLoc_depositVio.argtypes = [C.c_void_p, d, f, f, f, f]
+        self.L.particleFilterLoc_depositRange.argtypes = [C.c_void_p, f, f, f, f, f]
+        self.L.particleFilterLoc_depositRssi.argtypes = [C.c_void_p, f, f, f, C.c_int]
+        self.L.particleFilterSeed_set.argtypes = [C.c_uint]
+        self.buf = C.create_string_buffer(2 * self.N * 20 + 64)
+        self.p = C.cast(self.buf, C.c_void_p)
+        self.L.particleFilterSeed_set(123456789)
+        self.L.particleFilterLoc_init(self.p)
+
+    def depositVio(self, *a):
+        self.L.particleFilterLoc_depositVio(self.p, *a)
+
+    def depositRange(self, *a):
+        self.L.particleFilterLoc_depositRange(self.p, *a)
+
+    def depositRssi(self, *a):
+        self.L.particleFilterLoc_depositRssi(self.p, *a)
+
+
+def cpu_baseline(budget_s=12.0):
+    """Time the same workload on ONE host core, on a bounded sample (N = 1 M particles, as many steps as fit
+    the budget).  Prefers the compiled reference (kind "reference"); else the oracle restatement ("port")."""
+    n = 1000000
+    bx, truth, rng = scene(64)
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libpf_ref_glibc_n1m.so")
+    if os.path.exists(ref_so):
+        pf, kind = _RefLoc(ref_so), "reference"
+    else:
+        from oracle import oracle as ora
+        pf, kind = ora.OracleLoc(n, rng_mode=ora.RNG_GLIBC, seed=123456789, acc=ora.ACC_F32), "port"
+    pf.depositVio(999.9, float(truth[0, 0]), float(truth[0, 1]), float(truth[0, 2]), 0.0)
+    pf.depositRange(float(bx[0, 0]), float(bx[0, 1]), float(bx[0, 2]), float(rng[0, 0]), 0.1)   # init, untimed
+    t0 = time.perf_counter()
+    k = 0
+    while k < 60:
+        step(pf, k, bx, truth, rng)
+        k += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": 2.0 * n * k / dt, "unit": "particle-updates/s", "cores": 1, "kind": kind,
+            "sample": f"same scene and step, N=1,000,000 particles (1/16 of the GPU workload), {k} steps, "
+                      f"{dt:.1f} s, serial rand_r stream, float32 as the reference"}
+
+
+# ------------------------------------------------------------------ GPU run
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=16000000, help="particles per GPU")
+    ap.add_argument("--force-branch", type=int, default=-1, help="-1 reference test, 0 never resample, 1 always")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from slam3d_amd import particlefilter as pfm
+    K, W, n = args.steps, args.warmup, args.n
+    bx, truth, rng = scene(K + W + 1)
+
+    if world == 1:
+        pf = pfm.DeviceParticleFilterLoc(n, seed=123456789, stream_id=0, device=local)
+    else:
+        from slam3d_amd.sharded import ShardedLocFilter
+        pf = ShardedLocFilter(n * world, seed=123456789, device=local)
+    pf.set_force_branch(args.force_branch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # init (spawn) + warm-up, untimed
+    pf.depositVio(999.9, float(truth[0, 0]), float(truth[0, 1]), float(truth[0, 2]), 0.0)
+    pf.depositRange(float(bx[0, 0]), float(bx[0, 1]), float(bx[0, 2]), float(rng[0, 0]), 0.1)
+    for k in range(W):
+        step(pf, k, bx, truth, rng)
+    barrier()
+
+    pf.profile_begin(4 * K * 3 + 16)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        step(pf, k, bx, truth, rng)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    kinds, ms = pf.profile_records()
+    branches, total_dec = pf.branch_log()
+    branches = branches[-2 * K:]
+    pose = pf.getTagLoc()
+    err = float(np.linalg.norm(np.array(pose[2:5], dtype=np.float64) - truth[W + K - 1]))
+
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        names = pfm.DeviceParticleFilterLoc.KINDS
+        per = {}
+        for nm in ("stream", "stream_static", "resample"):
+            sel = ms[kinds == names.index(nm)]
+            if nm == "resample":
+                # a resample launch on a normalise-only step exits at once; count only the real ones,
+                # identified by the device-side branch log (one decision per launch, same order)
+                dec = branches[-sel.shape[0]:] if sel.shape[0] else branches[:0]
+                sel = sel[dec.astype(bool)] if dec.shape[0] == sel.shape[0] else sel
+            if sel.shape[0]:
+                avg_ms = float(sel.mean())
+                gbs = ALG_BYTES[nm] * n / (avg_ms * 1e-3) / 1e9
+                per[nm] = {"launches": int(sel.shape[0]), "avg_ms": avg_ms, "alg_bytes_per_particle": ALG_BYTES[nm],
+                           "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "total_ms": float(sel.sum())}
+        dominant = max(per, key=lambda k_: per[k_]["total_ms"]) if per else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if dominant and os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get(dominant, {}).get("hbm_bytes_per_launch")
+        roof = None
+        if dominant:
+            d = per[dominant]
+            roof = {"bound": "hbm", "kernel": "k_loc_" + ("resample" if dominant == "resample" else "stream"),
+                    "variant": dominant, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": d["frac"], "traffic": traffic, "avg_launch_ms": d["avg_ms"], "launches": d["launches"],
+                    "alg_bytes_per_particle": d["alg_bytes_per_particle"]}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        frac_a = float(branches.mean()) if branches.shape[0] else None
+        out = {
+            "metric": "particle-updates/sec (range update+resample) at N=16M",
+            "value": 2.0 * n * world * K / dt, "unit": "particle-updates/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config3: single-tag particleFilterLoc, 8 beacons, per step depositVio + depositRange "
+                                   "+ depositRssi (2 deposits = 2N particle-updates)",
+                       "particles_per_gpu": n, "particles_total": n * world,
+                       "parallelism": "single GPU" if world == 1 else f"one filter sharded by particle range over {world} GPUs, "
+                                                                       "RCCL all-gather of per-GPU sums per deposit",
+                       "force_branch": args.force_branch, "resample_fraction": frac_a,
+                       "rng": "Philox4x32-10 key 123456789", "final_position_error_m": err},
+            "roofline": roof, "kernels": per, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

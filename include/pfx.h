@@ -1,0 +1,110 @@
+/*
+ * pfx.h -- additive extension API of libparticlefilter.so (no counterpart in the reference unless a
+ * function says so).  The reference sizes every filter at compile time and offers no create/destroy,
+ * no error channel and no access to the pieces of a step; this header supplies those for the GPU
+ * implementation: runtime-N filters, explicit device/stream control, state upload/download, the
+ * individual stages of a step (for parity tests against the oracle), and kernel timing.
+ *
+ * Conventions: plain C ABI, host pointers unless a parameter is named d_* (device pointer);
+ * functions returning int give 0 on success and a negative code on failure, after which
+ * pfx_last_error() describes it.  A filter is not thread-safe (neither is the reference's:
+ * one global rand_r stream); all work of one filter is ordered on its own HIP stream and is
+ * asynchronous to the host except the calls that return data.
+ */
+#ifndef PFX_H
+#define PFX_H
+
+#include <stdint.h>
+#include "particleFilter.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pfx_loc pfx_loc;         /* a particleFilterLoc with its particles in HBM */
+
+/* Philox sub-stream selectors (counter word 3).  Same values as oracle/pf_oracle.h ORA_P_*. */
+enum { PFX_P_VIO = 1, PFX_P_RSTART = 2, PFX_P_JITTER = 3, PFX_P_SPAWN = 4 };
+
+/* kernel classes reported by pfx_loc_profile_read */
+enum { PFX_K_STREAM = 0,        /* k_loc_stream with VIO motion (reads and writes all five arrays) */
+       PFX_K_DECIDE = 1, PFX_K_RESAMPLE = 2, PFX_K_SPAWN = 3, PFX_K_POSE = 4,
+       PFX_K_STREAM_STATIC = 5, /* k_loc_stream without motion (writes the weights only) */
+       PFX_K_COUNT = 6 };
+
+/* ---- library ---- */
+const char* pfx_version(void);
+const char* pfx_last_error(void);                   /* thread-local, "" if none */
+int         pfx_device_count(void);                 /* gfx950 devices visible; 0 = none (every create fails) */
+
+/* ---- runtime-N Loc filter ---- */
+/* particleFilterLoc_init with a particle count and placement chosen at run time
+ * (reference: particleFilter.c:32-46, PF_N_TAG_LOC fixed at particleFilter.h:18).
+ * `stream_id` separates the noise of filters that share a seed (Philox key word 1). */
+pfx_loc* pfx_loc_create(int64_t n, uint32_t seed, uint32_t stream_id, int device);
+void     pfx_loc_destroy(pfx_loc* pf);
+int      pfx_loc_reset(pfx_loc* pf, uint32_t seed, uint32_t stream_id);   /* back to "not initialised" */
+int64_t  pfx_loc_n(const pfx_loc* pf);
+int      pfx_loc_device(const pfx_loc* pf);
+uint32_t pfx_loc_seed(const pfx_loc* pf);           /* Philox key word 0 */
+uint32_t pfx_loc_stream_id(const pfx_loc* pf);      /* Philox key word 1 */
+int      pfx_loc_set_stream(pfx_loc* pf, void* hip_stream);  /* run on a caller stream (e.g. torch's current one) */
+int      pfx_loc_sync(pfx_loc* pf);                           /* wait until queued kernels have finished */
+/* -1 (default): the reference's ESS / respawn test picks the branch (pfResample.c:58); 0: never resample;
+ * 1: resample on every deposit (the worst-case-traffic run of BASELINE.json config 3) */
+int      pfx_loc_set_force_branch(pfx_loc* pf, int force);
+
+/* the reference's four operations (particleFilter.c:70-104, 178-191, 213-226, 248-291) */
+void     pfx_loc_deposit_vio(pfx_loc* pf, double t, float x, float y, float z, float dist);
+int      pfx_loc_deposit_range(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);
+int      pfx_loc_deposit_rssi(pfx_loc* pf, float bx, float by, float bz, int rssi);
+int      pfx_loc_get_tag_loc(pfx_loc* pf, double* t, float* x, float* y, float* z, float* theta);  /* 1 ok, 0 not initialised, <0 error */
+
+/* ---- state access ---- */
+int      pfx_loc_upload(pfx_loc* pf, const float* w, const float* x, const float* y, const float* z,
+                        const float* theta, int64_t n, int initialized);
+int      pfx_loc_download(pfx_loc* pf, float* w, float* x, float* y, float* z, float* theta, int64_t n);
+int      pfx_loc_initialized(const pfx_loc* pf);
+uint32_t pfx_loc_epoch(const pfx_loc* pf);          /* Philox counter word 2: one per deposit */
+void     pfx_loc_set_epoch(pfx_loc* pf, uint32_t epoch);
+/* device pointers of the current SoA arrays (0=w 1=x 2=y 3=z 4=theta); synchronises the stream.
+ * w is stored without the pending normalisation factor: true weight = w * (*wscale). */
+int      pfx_loc_device_arrays(pfx_loc* pf, void* d_ptrs[5], float* wscale);
+
+/* ---- the stages of a step, one at a time (what the oracle's ora_loc_* pieces restate) ---- */
+int      pfx_loc_apply_vio(pfx_loc* pf, float dt, float dx, float dy, float dz, float ddist);           /* pfMeasurement.c:24-49 */
+int      pfx_loc_apply_range(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);   /* pfMeasurement.c:108-125 */
+int      pfx_loc_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);      /* pfResample.c:30-84 */
+int      pfx_loc_spawn_all(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);     /* pfInit.c:20-25 */
+/* out[0]=branch (1 resampled, 0 normalised) out[1]=numSpawn out[2..5]=s ss csum ssum (f32 totals)
+ * out[6]=ess out[7]=htheta out[8]=rStart out[9]=rStep out[10]=m (normalisation factor) out[11]=S (f64 total) */
+int      pfx_loc_last_stats(pfx_loc* pf, double out[12]);
+int      pfx_loc_record_ancestors(pfx_loc* pf, int enable);  /* keep the ancestor index of every offspring */
+int      pfx_loc_last_ancestors(pfx_loc* pf, int32_t* anc, int64_t n);
+
+/* systematic-resample index selection on a caller-supplied CDF (host arrays), as pfResample.c:70-72
+ * walks it: anc[i] = first j with rStart + rStep*i < cdf[j], clamped to n-1.  Runs the same device
+ * search the resample kernel uses.  Bit-exact against the reference loop for identical inputs. */
+int      pfx_resample_indices_f32(const float* cdf, int64_t n, float rStart, float rStep, int32_t* anc, int device);
+int      pfx_resample_indices_f64(const double* cdf, int64_t n, double rStart, double rStep, int32_t* anc, int device);
+
+/* ---- kernel timing (HIP events on the filter's stream) ---- */
+int      pfx_loc_profile_begin(pfx_loc* pf, int max_records);
+/* sums of elapsed ms and launch counts per kernel class since pfx_loc_profile_begin; stops recording */
+int      pfx_loc_profile_read(pfx_loc* pf, double ms[PFX_K_COUNT], int64_t launches[PFX_K_COUNT]);
+/* the same records one by one, in launch order (call before pfx_loc_profile_read, which clears them);
+ * returns the number of records written (<= cap), <0 on error */
+int64_t  pfx_loc_profile_records(pfx_loc* pf, int32_t* kind, float* ms, int64_t cap);
+/* branch taken by each deposit since creation (1 resampled, 0 normalised), oldest first, at most the
+ * last 65536; *total = number of decisions so far.  Synchronises the stream. */
+int64_t  pfx_loc_branch_log(pfx_loc* pf, uint8_t* out, int64_t cap, int64_t* total);
+
+/* ---- binding between the reference-layout structs and device filters ---- */
+pfx_loc* pfx_loc_of(const particleFilterLoc_t* pf);          /* NULL if the struct is not bound */
+int      pfx_loc_sync_host(particleFilterLoc_t* pf);         /* fill pf->pTag[] (AoS) from HBM */
+void     pfx_loc_release(particleFilterLoc_t* pf);           /* free the device side (the reference API has no destroy) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

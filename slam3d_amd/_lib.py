@@ -1,0 +1,95 @@
+"""Loader of the C-ABI library (slam3d_amd/lib/libparticlefilter.so).
+
+There is no Python or CPU implementation behind this package: if the library has not been built
+(`make -C slam3d_amd/csrc`, or `python -c "import __graft_entry__ as g; g.build()"`) importing the
+product modules fails, and creating a filter without a visible gfx950 device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libparticlefilter.so")
+
+_lib = None
+
+
+class PfxError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C slam3d_amd/csrc` "
+                          "(there is no fallback implementation)")
+    L = C.CDLL(LIB_PATH)
+    vp, f, d, i, i64, u32 = C.c_void_p, C.c_float, C.c_double, C.c_int, C.c_int64, C.c_uint32
+    pf_, pd_ = C.POINTER(C.c_float), C.POINTER(C.c_double)
+
+    def sig(name, res, *args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("pfx_version", C.c_char_p)
+    sig("pfx_last_error", C.c_char_p)
+    sig("pfx_device_count", i)
+    sig("pfx_loc_create", vp, i64, u32, u32, i)
+    sig("pfx_loc_destroy", None, vp)
+    sig("pfx_loc_reset", i, vp, u32, u32)
+    sig("pfx_loc_n", i64, vp)
+    sig("pfx_loc_device", i, vp)
+    sig("pfx_loc_seed", u32, vp)
+    sig("pfx_loc_stream_id", u32, vp)
+    sig("pfx_loc_set_stream", i, vp, vp)
+    sig("pfx_loc_sync", i, vp)
+    sig("pfx_loc_set_force_branch", i, vp, i)
+    sig("pfx_loc_deposit_vio", None, vp, d, f, f, f, f)
+    sig("pfx_loc_deposit_range", i, vp, f, f, f, f, f)
+    sig("pfx_loc_deposit_rssi", i, vp, f, f, f, i)
+    sig("pfx_loc_get_tag_loc", i, vp, pd_, pf_, pf_, pf_, pf_)
+    sig("pfx_loc_upload", i, vp, vp, vp, vp, vp, vp, i64, i)
+    sig("pfx_loc_download", i, vp, vp, vp, vp, vp, vp, i64)
+    sig("pfx_loc_initialized", i, vp)
+    sig("pfx_loc_epoch", u32, vp)
+    sig("pfx_loc_set_epoch", None, vp, u32)
+    sig("pfx_loc_device_arrays", i, vp, C.POINTER(vp), pf_)
+    sig("pfx_loc_apply_vio", i, vp, f, f, f, f, f)
+    sig("pfx_loc_apply_range", i, vp, f, f, f, f, f)
+    sig("pfx_loc_resample", i, vp, f, f, f, f, f)
+    sig("pfx_loc_spawn_all", i, vp, f, f, f, f, f)
+    sig("pfx_loc_last_stats", i, vp, pd_)
+    sig("pfx_loc_record_ancestors", i, vp, i)
+    sig("pfx_loc_last_ancestors", i, vp, vp, i64)
+    sig("pfx_resample_indices_f32", i, vp, i64, f, f, vp, i)
+    sig("pfx_resample_indices_f64", i, vp, i64, d, d, vp, i)
+    sig("pfx_loc_profile_begin", i, vp, i)
+    sig("pfx_loc_profile_read", i, vp, pd_, C.POINTER(i64))
+    sig("pfx_loc_profile_records", i64, vp, vp, vp, i64)
+    sig("pfx_loc_branch_log", i64, vp, vp, i64, C.POINTER(i64))
+    sig("pfx_loc_of", vp, vp)
+    sig("pfx_loc_sync_host", i, vp)
+    sig("pfx_loc_release", None, vp)
+    # reference-layout entry points (include/particleFilter.h)
+    sig("particleFilterSeed_set", None, C.c_uint)
+    sig("particleFilterLoc_init", None, vp)
+    sig("particleFilterLoc_depositVio", None, vp, d, f, f, f, f)
+    sig("particleFilterLoc_depositRange", None, vp, f, f, f, f, f)
+    sig("particleFilterLoc_depositRssi", None, vp, f, f, f, i)
+    sig("particleFilterLoc_getTagLoc", C.c_uint8, vp, pd_, pf_, pf_, pf_, pf_)
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().pfx_last_error().decode()
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        raise PfxError(f"{what}: {last_error()}")
+    return rc

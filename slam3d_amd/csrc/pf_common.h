@@ -1,0 +1,195 @@
+// pf_common.h -- device-side building blocks shared by the particle-filter kernels (gfx950).
+//
+// Arithmetic follows the reference's float32 expressions term by term; the translation units
+// are compiled with -ffp-contract=off so hipcc never fuses a multiply-add (the reference is built
+// for baseline x86-64, which has none).  Only the noise source differs: counter-based
+// Philox4x32-10 instead of the serial rand_r stream (pfRandom.c:26-49).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pf {
+
+constexpr int kThreads = 256;               // 4 wavefronts of 64
+constexpr int kPerThread = 4;               // one float4 per array per thread
+constexpr int kTile = kThreads * kPerThread; // 1024 particles per workgroup tile
+
+constexpr float kPi = 3.14159274101257324219f;      // (float)M_PI
+constexpr float kTwoPi = 6.28318548202514648438f;   // 2 * (float)M_PI  (pfMeasurement.c:47)
+constexpr float kInv2p31 = 4.656612873077392578125e-10f;  // 1 / 2^31, exact
+
+// pfMeasurement.c:20-22, pfResample.c:22-26
+constexpr float kVioStdXyz = 1e-3f;
+constexpr float kVioStdTheta = 1e-6f;
+constexpr float kResampleThresh = 0.5f;
+constexpr float kRadiusSpawnThresh = 4.0f;
+constexpr float kWeightSpawnThresh = 0.4f;
+constexpr float kPctSpawn = 0.05f;
+constexpr float kHxyz = 0.1f;
+
+enum : uint32_t { P_VIO = 1, P_RSTART = 2, P_JITTER = 3, P_SPAWN = 4 };
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct u32x4 { uint32_t a, b, c, d; };
+
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                       uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return { c0, c1, c2, c3 };
+}
+
+// The sub-stream of (seed, stream; epoch, purpose, particle index): block b supplies words 4b..4b+3.
+struct RngKey { uint32_t seed, stream, epoch; };
+
+__host__ __device__ __forceinline__ u32x4 rng_block(const RngKey& k, uint32_t purpose, uint64_t index, uint32_t block)
+{
+    return philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), k.epoch, purpose + 16u * block, k.seed, k.stream);
+}
+
+// rand_r_func() stand-in: a 31-bit value from one Philox word
+__host__ __device__ __forceinline__ uint32_t r31(uint32_t word) { return word >> 1; }
+
+// pfRandom.c:62-65 -- (float)r / RAND_MAX, RAND_MAX rounding to 2^31 in float: [0,1] inclusive
+__host__ __device__ __forceinline__ float uniform01(uint32_t word) { return (float)r31(word) * kInv2p31; }
+// pfRandom.c:100-103 -- (r + 1) / 2^31 in (0,1]
+__host__ __device__ __forceinline__ float uniform_nonzero(uint32_t word) { return (float)(r31(word) + 1u) * kInv2p31; }
+
+// pfRandom.c:67-74 -- Box-Muller pair from two words (u1 first)
+__device__ __forceinline__ void normal2(uint32_t w0, uint32_t w1, float& a, float& b)
+{
+    const float f = sqrtf(-2.0f * logf(uniform_nonzero(w0)));
+    const float g = uniform_nonzero(w1) * 2.0f * kPi;
+    float sn, cs;
+    sincosf(g, &sn, &cs);
+    a = f * cs;
+    b = f * sn;
+}
+
+// fmodf(x, 2*pi_f) with the result keeping x's sign (pfMeasurement.c:47, pfInit.c:78).  For
+// |x| < 4*pi the quotient is 0 or +-1 and |x| - 2*pi is exact (Sterbenz), so no division is needed;
+// anything larger (possible after a wide heading jitter) takes the library routine.
+__device__ __forceinline__ float wrap_two_pi(float x)
+{
+    const float ax = fabsf(x);
+    if (ax < kTwoPi) return x;
+    if (ax < 2.0f * kTwoPi) return copysignf(ax - kTwoPi, x);
+    return fmodf(x, kTwoPi);
+}
+
+// pfInit.c:56-66 + pfRandom.c:76-98 -- particle on the range shell around (cx,cy,cz), random heading.
+// Words are consumed in the reference's draw order: radius tries (first non-negative of up to 10),
+// elevation, azimuth, heading.
+__device__ __forceinline__ void spawn_from_range(const RngKey& key, uint64_t index, float cx, float cy, float cz,
+                                                 float range, float stdRange,
+                                                 float& x, float& y, float& z, float& theta)
+{
+    u32x4 blk = rng_block(key, P_SPAWN, index, 0);
+    uint32_t nblk = 1, pos = 0;
+    auto next = [&]() -> uint32_t {
+        if (pos == 4) { blk = rng_block(key, P_SPAWN, index, nblk++); pos = 0; }
+        const uint32_t v = pos == 0 ? blk.a : pos == 1 ? blk.b : pos == 2 ? blk.c : blk.d;
+        ++pos;
+        return v;
+    };
+    float rad = 0.0f;
+    for (int k = 0; k < 10; ++k) {
+        const float t = range + 3.0f * stdRange * (uniform01(next()) * 2.0f - 1.0f);
+        if (t < 0.0f) continue;
+        rad = t;
+        break;
+    }
+    const float elev = asinf(uniform01(next()) * 2.0f - 1.0f);
+    const float azim = uniform01(next()) * 2.0f * kPi;
+    float se, ce, sa, ca;
+    sincosf(elev, &se, &ce);
+    sincosf(azim, &sa, &ca);
+    const float c = rad * ce;
+    x = cx + c * ca;
+    y = cy + c * sa;
+    z = cz + rad * se;
+    theta = uniform01(next()) * 2.0f * kPi;
+}
+
+// pfInit.c:68-79 -- jittered copy of an ancestor (w = 1 is written by the caller)
+__device__ __forceinline__ void spawn_from_other(const RngKey& key, uint64_t index, float ox, float oy, float oz, float oth,
+                                                 float hXyz, float hTheta, float& x, float& y, float& z, float& theta)
+{
+    const u32x4 r = rng_block(key, P_JITTER, index, 0);
+    float dx, dy, dz, dth;
+    normal2(r.a, r.b, dx, dy);
+    normal2(r.c, r.d, dz, dth);
+    x = ox + dx * hXyz;
+    y = oy + dy * hXyz;
+    z = oz + dz * hXyz;
+    theta = wrap_two_pi(oth + dth * hTheta);
+}
+
+// ---------------------------------------------------------------- wave / block reductions (wave = 64)
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum K doubles per thread over a 256-thread block; result valid in thread 0.  `lds` holds 4*K doubles.
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double* lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) lds[wave * K + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
+    }
+}
+
+// Inclusive scan of one double per thread across a 256-thread block.  `lds` holds 4 doubles.
+__device__ __forceinline__ double block_inclusive_scan(double v, double* lds, double& block_total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double up = __shfl_up(v, off, 64);
+        if (lane >= off) v += up;
+    }
+    if (lane == 63) lds[wave] = v;
+    __syncthreads();
+    const double w0 = lds[0], w1 = lds[1], w2 = lds[2], w3 = lds[3];
+    double pre = 0.0;
+    if (wave > 0) pre = w0;
+    if (wave > 1) pre += w1;
+    if (wave > 2) pre += w2;
+    block_total = ((w0 + w1) + w2) + w3;
+    return v + pre;
+}
+
+// first j in [0, n) with u < cdf[j]; n-1 if there is none (pfResample.c:70-72 with the clamp)
+template <typename T>
+__device__ __forceinline__ int upper_bound_clamped(const T* cdf, int n, T u)
+{
+    int lo = 0, hi = n - 1;             // answer lies in [lo, hi]
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (u < cdf[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+}  // namespace pf

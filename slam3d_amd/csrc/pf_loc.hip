@@ -1,0 +1,753 @@
+// pf_loc.hip -- C-ABI of the particleFilterLoc hot path: the reference's entry points
+// (include/particleFilter.h) and the pfx_loc_* extension (include/pfx.h) over the HIP kernels.
+//
+// Host side of one filter: the VIO accumulator (O(1), particleFilter.c:70-104, 389-404) and the
+// launch sequence; everything O(N) runs on the GPU.  No CPU path exists: without a usable
+// gfx950 device creation fails (pfx_*) or the process aborts with a message (reference-layout API,
+// which has no way to report an error).
+#include "pf_loc_kernels.h"
+#include "pf_host.h"
+
+#include "../../include/pfx.h"
+
+#include <cmath>
+#include <ctime>
+#include <mutex>
+#include <new>
+#include <unordered_set>
+#include <vector>
+
+using namespace pf;
+
+// ------------------------------------------------------------------ error channel
+namespace pf {
+char* last_error_buf() { static thread_local char buf[512] = ""; return buf; }
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+}
+void clear_error() { last_error_buf()[0] = 0; }
+void die(const char* what)
+{
+    fprintf(stderr, "libparticlefilter: %s: %s\nlibparticlefilter: there is no CPU fallback; aborting.\n", what, last_error_buf());
+    abort();
+}
+}  // namespace pf
+
+extern "C" {
+unsigned int PF_SEED = 0;       // pfRandom.c:51-52
+int PF_SEED_SET = 0;
+}
+
+// ------------------------------------------------------------------ the filter object
+struct VioState {               // particleFilter.h:52-62 without the `initialized` byte
+    double firstT = 0.0; float firstX = 0, firstY = 0, firstZ = 0, firstDist = 0;
+    double lastT = 0.0;  float lastX = 0, lastY = 0, lastZ = 0, lastDist = 0;
+};
+
+static void vio_deposit(VioState& v, double t, float x, float y, float z, float dist)
+{   // particleFilter.c:70-104
+    if (v.firstT == 0.0) {
+        v.firstT = v.lastT = t;
+        v.firstX = v.lastX = x; v.firstY = v.lastY = y; v.firstZ = v.lastZ = z;
+        v.firstDist = v.lastDist = dist;
+        return;
+    }
+    if (dist > v.lastDist) {
+        v.lastDist = dist;
+    } else {
+        const float dx = x - v.lastX, dy = y - v.lastY, dz = z - v.lastZ;
+        v.lastDist += sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+    v.lastT = t; v.lastX = x; v.lastY = y; v.lastZ = z;
+}
+
+static void vio_commit(VioState& v, float d[5])
+{   // particleFilter.c:389-404
+    d[0] = (float)(v.lastT - v.firstT);
+    d[1] = v.lastX - v.firstX; d[2] = v.lastY - v.firstY; d[3] = v.lastZ - v.firstZ;
+    d[4] = v.lastDist - v.firstDist;
+    v.firstT = v.lastT; v.firstX = v.lastX; v.firstY = v.lastY; v.firstZ = v.lastZ; v.firstDist = v.lastDist;
+}
+
+struct ProfRec { hipEvent_t a, b; int kind; };
+
+struct pfx_loc {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    long long n = 0;
+    int numTiles = 0;
+    size_t padded = 0;
+    float* slab = nullptr;          // 10 arrays of `padded` floats
+    LocBufs bufs{};
+    double* tileSums = nullptr;     // numTiles * kSumsPerTile
+    double* rsPart = nullptr;       // numTiles * kRsPerTile
+    double* tileBase = nullptr;     // numTiles + 1
+    long long* firstOut = nullptr;  // numTiles + 1
+    unsigned char* branchLog = nullptr; // kBranchLogSize
+    int* anc = nullptr;             // n, only while recording
+    bool recordAnc = false;
+    LocCtl* ctl = nullptr;
+    LocCtl* hostCtl = nullptr;      // pinned
+    uint32_t seed = 0, streamId = 0, epoch = 0;
+    bool initialized = false;
+    bool poseDirty = true;
+    int force = -1;
+    VioState vio;
+    // profiling
+    std::vector<ProfRec> prof;
+    size_t profUsed = 0;
+    bool profOn = false;
+};
+
+static std::mutex g_mu;
+static std::unordered_set<pfx_loc*> g_live;
+static uint32_t g_nextStream = 0;
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { hipGetDevice(&prev); if (prev != dev) hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+
+struct ProfScope {
+    pfx_loc* pf; ProfRec* r = nullptr;
+    ProfScope(pfx_loc* p, int kind) : pf(p)
+    {
+        if (pf->profOn && pf->profUsed < pf->prof.size()) {
+            r = &pf->prof[pf->profUsed++];
+            r->kind = kind;
+            hipEventRecord(r->a, pf->stream);
+        }
+    }
+    ~ProfScope() { if (r) hipEventRecord(r->b, pf->stream); }
+};
+
+RngKey key_of(const pfx_loc* pf) { return RngKey{ pf->seed, pf->streamId, pf->epoch }; }
+
+int check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("launch of %s failed: %s", what, hipGetErrorString(e)); return -1; }
+    return 0;
+}
+
+int launch_set_ctl(pfx_loc* pf, int cur, int branch, float wscale, int keepCur)
+{
+    hipLaunchKernelGGL(k_loc_set_ctl, dim3(1), dim3(64), 0, pf->stream, pf->ctl, cur, branch, wscale, keepCur);
+    return check_launch("k_loc_set_ctl");
+}
+
+int launch_stream(pfx_loc* pf, bool motion, bool gate, const Motion& mo, const Gate& ga)
+{
+    ProfScope ps(pf, motion ? PFX_K_STREAM : PFX_K_STREAM_STATIC);
+    const dim3 grid(pf->numTiles), block(kThreads);
+    const RngKey key = key_of(pf);
+#define PF_LAUNCH_STREAM(M, G) \
+    hipLaunchKernelGGL((k_loc_stream<M, G>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->tileSums, pf->n, key, mo, ga)
+    if (motion && gate) PF_LAUNCH_STREAM(true, true);
+    else if (motion) PF_LAUNCH_STREAM(true, false);
+    else if (gate) PF_LAUNCH_STREAM(false, true);
+    else PF_LAUNCH_STREAM(false, false);
+#undef PF_LAUNCH_STREAM
+    return check_launch("k_loc_stream");
+}
+
+int launch_decide(pfx_loc* pf, float range)
+{
+    ProfScope ps(pf, PFX_K_DECIDE);
+    hipLaunchKernelGGL(k_loc_decide, dim3(1), dim3(kDecideThreads), 0, pf->stream, pf->ctl, pf->tileSums, pf->tileBase,
+                       pf->firstOut, pf->numTiles, pf->n, range, key_of(pf), pf->force, pf->branchLog);
+    return check_launch("k_loc_decide");
+}
+
+int launch_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+{
+    ProfScope ps(pf, PFX_K_RESAMPLE);
+    const dim3 grid(pf->numTiles), block(kThreads);
+    if (pf->recordAnc)
+        hipLaunchKernelGGL((k_loc_resample<true>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->tileBase, pf->firstOut,
+                           pf->rsPart, pf->anc, pf->n, key_of(pf), bx, by, bz, range, stdRange);
+    else
+        hipLaunchKernelGGL((k_loc_resample<false>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->tileBase, pf->firstOut,
+                           pf->rsPart, (int*)nullptr, pf->n, key_of(pf), bx, by, bz, range, stdRange);
+    return check_launch("k_loc_resample");
+}
+
+int launch_spawn(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+{
+    if (launch_set_ctl(pf, 0, 1, 1.0f, 0)) return -1;
+    ProfScope ps(pf, PFX_K_SPAWN);
+    hipLaunchKernelGGL(k_loc_spawn, dim3(pf->numTiles), dim3(kThreads), 0, pf->stream, pf->bufs, pf->ctl, pf->rsPart, pf->n,
+                       key_of(pf), bx, by, bz, range, stdRange);
+    return check_launch("k_loc_spawn");
+}
+
+Motion motion_of(const float d[5])
+{   // pfMeasurement.c:31-32
+    return Motion{ d[1], d[2], d[3], sqrtf(d[4]) * kVioStdXyz, sqrtf(d[0]) * kVioStdTheta };
+}
+bool is_zero_motion(const float d[5])
+{   // exact zeros only: then x,y,z are unchanged bit for bit and theta only wraps (NaN compares false -> motion)
+    return d[0] == 0.0f && d[1] == 0.0f && d[2] == 0.0f && d[3] == 0.0f && d[4] == 0.0f;
+}
+Gate gate_of(float bx, float by, float bz, float range, float stdRange)
+{   // pfMeasurement.c:22,114,122
+    return Gate{ bx, by, bz, range, 3 * stdRange, (range < 3.0f) ? 0.1f : 0.5f };
+}
+
+int read_ctl(pfx_loc* pf)
+{
+    PF_HIP_OK(hipMemcpyAsync(pf->hostCtl, pf->ctl, sizeof(LocCtl), hipMemcpyDeviceToHost, pf->stream));
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    return 0;
+}
+
+void free_device(pfx_loc* pf)
+{
+    if (pf->slab) hipFree(pf->slab);
+    if (pf->tileSums) hipFree(pf->tileSums);
+    if (pf->rsPart) hipFree(pf->rsPart);
+    if (pf->tileBase) hipFree(pf->tileBase);
+    if (pf->firstOut) hipFree(pf->firstOut);
+    if (pf->anc) hipFree(pf->anc);
+    if (pf->branchLog) hipFree(pf->branchLog);
+    if (pf->ctl) hipFree(pf->ctl);
+    if (pf->hostCtl) hipHostFree(pf->hostCtl);
+    for (auto& r : pf->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    pf->prof.clear();
+    if (pf->ownStream && pf->stream) hipStreamDestroy(pf->stream);
+}
+
+int alloc_device(pfx_loc* pf)
+{
+    PF_HIP_OK(hipStreamCreateWithFlags(&pf->stream, hipStreamNonBlocking));
+    pf->ownStream = true;
+    const size_t slabBytes = pf->padded * 10 * sizeof(float);
+    PF_HIP_OK(hipMalloc((void**)&pf->slab, slabBytes));
+    PF_HIP_OK(hipMemsetAsync(pf->slab, 0, slabBytes, pf->stream));
+    for (int b = 0; b < 2; ++b)
+        for (int k = 0; k < 5; ++k) pf->bufs.a[b][k] = pf->slab + (size_t)(b * 5 + k) * pf->padded;
+    const size_t nt = (size_t)pf->numTiles;
+    PF_HIP_OK(hipMalloc((void**)&pf->tileSums, nt * kSumsPerTile * sizeof(double)));
+    PF_HIP_OK(hipMalloc((void**)&pf->rsPart, nt * kRsPerTile * sizeof(double)));
+    PF_HIP_OK(hipMalloc((void**)&pf->tileBase, (nt + 1) * sizeof(double)));
+    PF_HIP_OK(hipMalloc((void**)&pf->firstOut, (nt + 1) * sizeof(long long)));
+    PF_HIP_OK(hipMemsetAsync(pf->tileSums, 0, nt * kSumsPerTile * sizeof(double), pf->stream));
+    PF_HIP_OK(hipMemsetAsync(pf->rsPart, 0, nt * kRsPerTile * sizeof(double), pf->stream));
+    PF_HIP_OK(hipMalloc((void**)&pf->branchLog, kBranchLogSize));
+    PF_HIP_OK(hipMemsetAsync(pf->branchLog, 0, kBranchLogSize, pf->stream));
+    PF_HIP_OK(hipMalloc((void**)&pf->ctl, sizeof(LocCtl)));
+    PF_HIP_OK(hipMemsetAsync(pf->ctl, 0, sizeof(LocCtl), pf->stream));
+    PF_HIP_OK(hipHostMalloc((void**)&pf->hostCtl, sizeof(LocCtl), hipHostMallocDefault));
+    if (launch_set_ctl(pf, 0, 0, 1.0f, 0)) return -1;
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ library
+extern "C" const char* pfx_version(void) { return "slam3d_amd particlefilter 0.1 (gfx950)"; }
+extern "C" const char* pfx_last_error(void) { return last_error_buf(); }
+
+extern "C" int pfx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// ------------------------------------------------------------------ create / destroy
+extern "C" pfx_loc* pfx_loc_create(int64_t n, uint32_t seed, uint32_t stream_id, int device)
+{
+    clear_error();
+    if (n < 1 || n > (int64_t)1 << 31) { set_error("pfx_loc_create: n=%lld out of range [1, 2^31]", (long long)n); return nullptr; }
+    const int ndev = pfx_device_count();
+    if (ndev <= 0) { set_error("pfx_loc_create: no HIP device visible"); return nullptr; }
+    if (device < 0 || device >= ndev) { set_error("pfx_loc_create: device %d not in [0,%d)", device, ndev); return nullptr; }
+    pfx_loc* pf = new (std::nothrow) pfx_loc();
+    if (!pf) { set_error("pfx_loc_create: out of host memory"); return nullptr; }
+    pf->device = device;
+    pf->n = n;
+    pf->numTiles = (int)((n + kTile - 1) / kTile);
+    pf->padded = (size_t)pf->numTiles * kTile;
+    pf->seed = seed;
+    pf->streamId = stream_id;
+    DeviceGuard g(device);
+    if (alloc_device(pf)) { free_device(pf); delete pf; return nullptr; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_live.insert(pf);
+    return pf;
+}
+
+extern "C" void pfx_loc_destroy(pfx_loc* pf)
+{
+    if (!pf) return;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_live.erase(pf)) return;
+    }
+    DeviceGuard g(pf->device);
+    if (pf->stream) hipStreamSynchronize(pf->stream);
+    free_device(pf);
+    delete pf;
+}
+
+extern "C" int pfx_loc_reset(pfx_loc* pf, uint32_t seed, uint32_t stream_id)
+{   // particleFilter.c:32-46: scalars zeroed, not initialised; the particle arrays are left as they are
+    clear_error();
+    pf->vio = VioState();
+    pf->initialized = false;
+    pf->seed = seed;
+    pf->streamId = stream_id;
+    pf->epoch = 0;
+    pf->poseDirty = true;
+    return 0;
+}
+
+extern "C" int64_t pfx_loc_n(const pfx_loc* pf) { return pf->n; }
+extern "C" int pfx_loc_device(const pfx_loc* pf) { return pf->device; }
+extern "C" int pfx_loc_initialized(const pfx_loc* pf) { return pf->initialized ? 1 : 0; }
+extern "C" uint32_t pfx_loc_epoch(const pfx_loc* pf) { return pf->epoch; }
+extern "C" uint32_t pfx_loc_seed(const pfx_loc* pf) { return pf->seed; }
+extern "C" uint32_t pfx_loc_stream_id(const pfx_loc* pf) { return pf->streamId; }
+extern "C" void pfx_loc_set_epoch(pfx_loc* pf, uint32_t e) { pf->epoch = e; }
+
+extern "C" int pfx_loc_set_stream(pfx_loc* pf, void* hip_stream)
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    if (pf->ownStream) { hipStreamDestroy(pf->stream); pf->ownStream = false; }
+    pf->stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+extern "C" int pfx_loc_sync(pfx_loc* pf)
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    return 0;
+}
+
+extern "C" int pfx_loc_set_force_branch(pfx_loc* pf, int force)
+{   // -1: the reference's ESS / respawn test decides; 0: never resample; 1: resample on every deposit
+    pf->force = force < 0 ? -1 : (force ? 1 : 0);
+    return 0;
+}
+
+// ------------------------------------------------------------------ the reference's four operations
+extern "C" void pfx_loc_deposit_vio(pfx_loc* pf, double t, float x, float y, float z, float dist)
+{
+    vio_deposit(pf->vio, t, x, y, z, dist);
+}
+
+extern "C" int pfx_loc_deposit_range(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+{   // particleFilter.c:178-191
+    clear_error();
+    DeviceGuard g(pf->device);
+    float d[5];
+    pf->epoch++;
+    vio_commit(pf->vio, d);
+    pf->poseDirty = true;
+    if (!pf->initialized) {
+        // The reference also runs the VIO update here, over the not-yet-spawned array; its only lasting
+        // effect is to advance the rand_r stream, which a counter-based generator has no equivalent of.
+        if (launch_spawn(pf, bx, by, bz, range, stdRange)) return -1;
+        pf->initialized = true;
+        return 0;
+    }
+    if (launch_stream(pf, !is_zero_motion(d), true, motion_of(d), gate_of(bx, by, bz, range, stdRange))) return -1;
+    if (launch_decide(pf, range)) return -1;
+    return launch_resample(pf, bx, by, bz, range, stdRange);
+}
+
+extern "C" int pfx_loc_deposit_rssi(pfx_loc* pf, float bx, float by, float bz, int rssi)
+{   // particleFilter.c:213-226: the rssi value is not used; a 1.5 m +- 0.5 m range is applied
+    (void)rssi;
+    return pfx_loc_deposit_range(pf, bx, by, bz, 1.5f, 0.5f);
+}
+
+extern "C" int pfx_loc_get_tag_loc(pfx_loc* pf, double* t, float* x, float* y, float* z, float* theta)
+{   // particleFilter.c:248-291
+    clear_error();
+    if (!pf->initialized) return 0;
+    DeviceGuard g(pf->device);
+    if (pf->poseDirty) {
+        {
+            ProfScope ps(pf, PFX_K_POSE);
+            hipLaunchKernelGGL(k_loc_pose, dim3(1), dim3(kThreads), 0, pf->stream, pf->ctl, pf->tileSums, pf->rsPart,
+                               pf->numTiles, pf->n);
+            if (check_launch("k_loc_pose")) return -1;
+        }
+        if (read_ctl(pf)) return -1;
+        pf->poseDirty = false;
+    }
+    const double* p = pf->hostCtl->pose;
+    const float s = (float)p[0], xs = (float)p[1], ys = (float)p[2], zs = (float)p[3], cs = (float)p[4], sn = (float)p[5];
+    *t = pf->vio.lastT;
+    *x = xs / s;
+    *y = ys / s;
+    *z = zs / s;
+    *theta = atan2f(sn, cs);
+    const float dx = pf->vio.lastX - pf->vio.firstX, dy = pf->vio.lastY - pf->vio.firstY, dz = pf->vio.lastZ - pf->vio.firstZ;
+    const float co = cosf(*theta), si = sinf(*theta);
+    *x += dx * co - dy * si;
+    *y += dx * si + dy * co;
+    *z += dz;
+    return 1;
+}
+
+// ------------------------------------------------------------------ state access
+extern "C" int pfx_loc_upload(pfx_loc* pf, const float* w, const float* x, const float* y, const float* z,
+                              const float* theta, int64_t n, int initialized)
+{
+    clear_error();
+    if (n != pf->n) { set_error("pfx_loc_upload: n=%lld but the filter holds %lld", (long long)n, pf->n); return -2; }
+    DeviceGuard g(pf->device);
+    const float* src[5] = { w, x, y, z, theta };
+    PF_HIP_OK(hipMemsetAsync(pf->slab, 0, pf->padded * 5 * sizeof(float), pf->stream));
+    for (int k = 0; k < 5; ++k)
+        PF_HIP_OK(hipMemcpyAsync(pf->bufs.a[0][k], src[k], (size_t)n * sizeof(float), hipMemcpyHostToDevice, pf->stream));
+    if (launch_set_ctl(pf, 0, 0, 1.0f, 0)) return -1;
+    // refresh the per-tile sums so that a pose query right after an upload is served
+    float zero[5] = { 0, 0, 0, 0, 0 };
+    if (launch_stream(pf, false, false, motion_of(zero), Gate{})) return -1;
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    pf->initialized = initialized != 0;
+    pf->poseDirty = true;
+    return 0;
+}
+
+extern "C" int pfx_loc_download(pfx_loc* pf, float* w, float* x, float* y, float* z, float* theta, int64_t n)
+{
+    clear_error();
+    if (n != pf->n) { set_error("pfx_loc_download: n=%lld but the filter holds %lld", (long long)n, pf->n); return -2; }
+    DeviceGuard g(pf->device);
+    if (read_ctl(pf)) return -1;
+    const int cur = pf->hostCtl->cur;
+    float* dst[5] = { w, x, y, z, theta };
+    for (int k = 0; k < 5; ++k)
+        if (dst[k]) PF_HIP_OK(hipMemcpyAsync(dst[k], pf->bufs.a[cur][k], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, pf->stream));
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    if (w) {
+        const float m = pf->hostCtl->wscale;        // pending w *= N/s of a normalise-only step (pfResample.c:80-82)
+        if (m != 1.0f)
+            for (int64_t i = 0; i < n; ++i) w[i] *= m;
+    }
+    return 0;
+}
+
+extern "C" int pfx_loc_device_arrays(pfx_loc* pf, void* d_ptrs[5], float* wscale)
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    if (read_ctl(pf)) return -1;
+    for (int k = 0; k < 5; ++k) d_ptrs[k] = pf->bufs.a[pf->hostCtl->cur][k];
+    if (wscale) *wscale = pf->hostCtl->wscale;
+    return 0;
+}
+
+// ------------------------------------------------------------------ stages of a step
+extern "C" int pfx_loc_apply_vio(pfx_loc* pf, float dt, float dx, float dy, float dz, float ddist)
+{   // pfMeasurement.c:24-49 (always the full update, also for zero motion)
+    clear_error();
+    DeviceGuard g(pf->device);
+    const float d[5] = { dt, dx, dy, dz, ddist };
+    if (launch_stream(pf, true, false, motion_of(d), Gate{})) return -1;
+    pf->poseDirty = true;
+    return launch_set_ctl(pf, 0, 0, 1.0f, 1);
+}
+
+extern "C" int pfx_loc_apply_range(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+{   // pfMeasurement.c:108-125
+    clear_error();
+    DeviceGuard g(pf->device);
+    const float zero[5] = { 0, 0, 0, 0, 0 };
+    if (launch_stream(pf, false, true, motion_of(zero), gate_of(bx, by, bz, range, stdRange))) return -1;
+    pf->poseDirty = true;
+    return launch_set_ctl(pf, 0, 0, 1.0f, 1);
+}
+
+extern "C" int pfx_loc_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+{   // pfResample.c:30-84
+    clear_error();
+    DeviceGuard g(pf->device);
+    const float zero[5] = { 0, 0, 0, 0, 0 };
+    if (launch_stream(pf, false, false, motion_of(zero), Gate{})) return -1;
+    if (launch_decide(pf, range)) return -1;
+    pf->poseDirty = true;
+    return launch_resample(pf, bx, by, bz, range, stdRange);
+}
+
+extern "C" int pfx_loc_spawn_all(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+{   // pfInit.c:20-25
+    clear_error();
+    DeviceGuard g(pf->device);
+    pf->poseDirty = true;
+    return launch_spawn(pf, bx, by, bz, range, stdRange);
+}
+
+extern "C" int pfx_loc_last_stats(pfx_loc* pf, double out[12])
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    if (read_ctl(pf)) return -1;
+    const LocCtl* c = pf->hostCtl;
+    out[0] = c->branch; out[1] = c->numSpawn; out[2] = c->s; out[3] = c->ss; out[4] = c->csum; out[5] = c->ssum;
+    out[6] = c->ess; out[7] = c->htheta; out[8] = c->rStart; out[9] = c->rStep; out[10] = c->m; out[11] = c->S;
+    return 0;
+}
+
+extern "C" int pfx_loc_record_ancestors(pfx_loc* pf, int enable)
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    if (enable && !pf->anc) PF_HIP_OK(hipMalloc((void**)&pf->anc, (size_t)pf->n * sizeof(int)));
+    pf->recordAnc = enable != 0;
+    return 0;
+}
+
+extern "C" int pfx_loc_last_ancestors(pfx_loc* pf, int32_t* anc, int64_t n)
+{
+    clear_error();
+    if (!pf->anc || n != pf->n) { set_error("pfx_loc_last_ancestors: recording is off or n mismatch"); return -2; }
+    DeviceGuard g(pf->device);
+    PF_HIP_OK(hipMemcpyAsync(anc, pf->anc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, pf->stream));
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    return 0;
+}
+
+template <typename T>
+static int resample_indices_impl(const T* cdf, int64_t n, T rStart, T rStep, int32_t* anc, int device)
+{
+    clear_error();
+    if (n < 1 || n > (int64_t)1 << 31) { set_error("pfx_resample_indices: n out of range"); return -2; }
+    if (device < 0 || device >= pfx_device_count()) { set_error("pfx_resample_indices: no such device %d", device); return -2; }
+    DeviceGuard g(device);
+    T* dCdf = nullptr;
+    int* dAnc = nullptr;
+    PF_HIP_OK(hipMalloc((void**)&dCdf, (size_t)n * sizeof(T)));
+    if (hipMalloc((void**)&dAnc, (size_t)n * sizeof(int)) != hipSuccess) { hipFree(dCdf); set_error("hipMalloc failed"); return -1; }
+    int rc = 0;
+    do {
+        if (hipMemcpy(dCdf, cdf, (size_t)n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { rc = -1; break; }
+        hipLaunchKernelGGL((k_resample_indices<T>), dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, 0,
+                           dCdf, (long long)n, rStart, rStep, dAnc);
+        if (check_launch("k_resample_indices")) { rc = -1; break; }
+        if (hipMemcpy(anc, dAnc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { rc = -1; break; }
+    } while (0);
+    if (rc && !last_error_buf()[0]) set_error("pfx_resample_indices: copy failed: %s", hipGetErrorString(hipGetLastError()));
+    hipFree(dCdf);
+    hipFree(dAnc);
+    return rc;
+}
+
+extern "C" int pfx_resample_indices_f32(const float* cdf, int64_t n, float rStart, float rStep, int32_t* anc, int device)
+{
+    return resample_indices_impl<float>(cdf, n, rStart, rStep, anc, device);
+}
+extern "C" int pfx_resample_indices_f64(const double* cdf, int64_t n, double rStart, double rStep, int32_t* anc, int device)
+{
+    return resample_indices_impl<double>(cdf, n, rStart, rStep, anc, device);
+}
+
+// ------------------------------------------------------------------ kernel timing
+extern "C" int pfx_loc_profile_begin(pfx_loc* pf, int max_records)
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    while ((int)pf->prof.size() < max_records) {
+        ProfRec r{};
+        PF_HIP_OK(hipEventCreate(&r.a));
+        PF_HIP_OK(hipEventCreate(&r.b));
+        pf->prof.push_back(r);
+    }
+    pf->profUsed = 0;
+    pf->profOn = true;
+    return 0;
+}
+
+extern "C" int pfx_loc_profile_read(pfx_loc* pf, double ms[PFX_K_COUNT], int64_t launches[PFX_K_COUNT])
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    pf->profOn = false;
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    for (int k = 0; k < PFX_K_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; }
+    for (size_t i = 0; i < pf->profUsed; ++i) {
+        float t = 0.0f;
+        PF_HIP_OK(hipEventElapsedTime(&t, pf->prof[i].a, pf->prof[i].b));
+        ms[pf->prof[i].kind] += t;
+        launches[pf->prof[i].kind] += 1;
+    }
+    pf->profUsed = 0;
+    return 0;
+}
+
+extern "C" int64_t pfx_loc_profile_records(pfx_loc* pf, int32_t* kind, float* ms, int64_t cap)
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    int64_t k = 0;
+    for (size_t i = 0; i < pf->profUsed && k < cap; ++i, ++k) {
+        float t = 0.0f;
+        PF_HIP_OK(hipEventElapsedTime(&t, pf->prof[i].a, pf->prof[i].b));
+        kind[k] = pf->prof[i].kind;
+        ms[k] = t;
+    }
+    return k;
+}
+
+extern "C" int64_t pfx_loc_branch_log(pfx_loc* pf, uint8_t* out, int64_t cap, int64_t* total)
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    if (read_ctl(pf)) return -1;
+    const long long nd = pf->hostCtl->nDecisions;
+    if (total) *total = nd;
+    long long have = nd < kBranchLogSize ? nd : kBranchLogSize;
+    if (have > cap) have = cap;
+    std::vector<unsigned char> ring(kBranchLogSize);
+    PF_HIP_OK(hipMemcpy(ring.data(), pf->branchLog, kBranchLogSize, hipMemcpyDeviceToHost));
+    for (long long i = 0; i < have; ++i) out[i] = ring[(size_t)((nd - have + i) % kBranchLogSize)];
+    return have;
+}
+
+// ------------------------------------------------------------------ reference-layout API (particleFilterLoc_*)
+namespace {
+
+// Binding record kept in the first bytes of pTagBuf (scratch in the reference, pfResample.c:72-74).
+struct LocStash { uint64_t magic; uint64_t self; pfx_loc* handle; };
+constexpr uint64_t kLocMagic = 0x70664C6F63484950ull;   // "pfLocHIP"
+
+LocStash* stash_of(const particleFilterLoc_t* pf) { return reinterpret_cast<LocStash*>(const_cast<tagParticle_t*>(pf->pTagBuf)); }
+
+pfx_loc* bound(const particleFilterLoc_t* pf)
+{
+    const LocStash* s = stash_of(pf);
+    if (s->magic != kLocMagic || s->self != (uint64_t)(uintptr_t)pf) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_live.count(s->handle) ? s->handle : nullptr;
+}
+
+pfx_loc* must_be_bound(const particleFilterLoc_t* pf, const char* fn)
+{
+    pfx_loc* h = bound(pf);
+    if (!h) { set_error("%s: struct %p was not initialised with particleFilterLoc_init (or was moved)", fn, (const void*)pf); die(fn); }
+    return h;
+}
+
+int64_t legacy_n()
+{   // particle count behind the reference-layout structs; PF_N_TAG_LOC unless overridden for scale-up runs
+    const char* e = getenv("PF_HIP_N_TAG_LOC");
+    if (e && *e) { const long long v = atoll(e); if (v > 0) return v; }
+    return PF_N_TAG_LOC;
+}
+int legacy_device()
+{
+    const char* e = getenv("PF_HIP_DEVICE");
+    return (e && *e) ? atoi(e) : 0;
+}
+
+void sync_scalars(particleFilterLoc_t* pf, const pfx_loc* h)
+{
+    pf->initialized = h->initialized ? 1 : 0;
+    pf->firstT = h->vio.firstT; pf->firstX = h->vio.firstX; pf->firstY = h->vio.firstY; pf->firstZ = h->vio.firstZ;
+    pf->firstDist = h->vio.firstDist;
+    pf->lastT = h->vio.lastT; pf->lastX = h->vio.lastX; pf->lastY = h->vio.lastY; pf->lastZ = h->vio.lastZ;
+    pf->lastDist = h->vio.lastDist;
+}
+
+// The reference API has no destroy.  Device memory still bound at process exit is reclaimed by the
+// driver; nothing is freed from a static destructor, because the HIP runtime may already be gone then.
+
+}  // namespace
+
+extern "C" void particleFilterSeed_set(unsigned int seed)
+{   // particleFilter.c:26-30
+    PF_SEED = seed;
+    PF_SEED_SET = 1;
+}
+
+extern "C" void particleFilterLoc_init(particleFilterLoc_t* pf)
+{   // particleFilter.c:32-46 + pfRandom.c:56-60 (seed from the clock unless one was set)
+    if (!PF_SEED_SET) PF_SEED = (unsigned int)time(nullptr);
+    uint32_t sid;
+    { std::lock_guard<std::mutex> lk(g_mu); sid = g_nextStream++; }
+    pfx_loc* h = bound(pf);
+    if (h) {
+        pfx_loc_reset(h, PF_SEED, sid);
+    } else {
+        h = pfx_loc_create(legacy_n(), PF_SEED, sid, legacy_device());
+        if (!h) die("particleFilterLoc_init");
+        LocStash* s = stash_of(pf);
+        s->magic = kLocMagic; s->self = (uint64_t)(uintptr_t)pf; s->handle = h;
+    }
+    sync_scalars(pf, h);
+}
+
+extern "C" void particleFilterLoc_depositVio(particleFilterLoc_t* pf, double t, float x, float y, float z, float dist)
+{
+    pfx_loc* h = must_be_bound(pf, "particleFilterLoc_depositVio");
+    pfx_loc_deposit_vio(h, t, x, y, z, dist);
+    sync_scalars(pf, h);
+}
+
+extern "C" void particleFilterLoc_depositRange(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
+{
+    pfx_loc* h = must_be_bound(pf, "particleFilterLoc_depositRange");
+    if (pfx_loc_deposit_range(h, bx, by, bz, range, stdRange)) die("particleFilterLoc_depositRange");
+    sync_scalars(pf, h);
+}
+
+extern "C" void particleFilterLoc_depositRssi(particleFilterLoc_t* pf, float bx, float by, float bz, int rssi)
+{
+    pfx_loc* h = must_be_bound(pf, "particleFilterLoc_depositRssi");
+    if (pfx_loc_deposit_rssi(h, bx, by, bz, rssi)) die("particleFilterLoc_depositRssi");
+    sync_scalars(pf, h);
+}
+
+extern "C" uint8_t particleFilterLoc_getTagLoc(const particleFilterLoc_t* pf, double* t, float* x, float* y, float* z, float* theta)
+{
+    pfx_loc* h = must_be_bound(pf, "particleFilterLoc_getTagLoc");
+    const int rc = pfx_loc_get_tag_loc(h, t, x, y, z, theta);
+    if (rc < 0) die("particleFilterLoc_getTagLoc");
+    return (uint8_t)rc;
+}
+
+extern "C" pfx_loc* pfx_loc_of(const particleFilterLoc_t* pf) { return bound(pf); }
+
+extern "C" int pfx_loc_sync_host(particleFilterLoc_t* pf)
+{   // fill the caller-visible AoS array from HBM (first PF_N_TAG_LOC particles if the filter holds more)
+    clear_error();
+    pfx_loc* h = bound(pf);
+    if (!h) { set_error("pfx_loc_sync_host: struct is not bound"); return -2; }
+    const int64_t n = h->n;
+    std::vector<float> tmp((size_t)n * 5);
+    if (pfx_loc_download(h, &tmp[0], &tmp[n], &tmp[2 * n], &tmp[3 * n], &tmp[4 * n], n)) return -1;
+    const int64_t m = n < PF_N_TAG_LOC ? n : PF_N_TAG_LOC;
+    for (int64_t i = 0; i < m; ++i) {
+        pf->pTag[i].w = tmp[i]; pf->pTag[i].x = tmp[n + i]; pf->pTag[i].y = tmp[2 * n + i];
+        pf->pTag[i].z = tmp[3 * n + i]; pf->pTag[i].theta = tmp[4 * n + i];
+    }
+    sync_scalars(pf, h);
+    return 0;
+}
+
+extern "C" void pfx_loc_release(particleFilterLoc_t* pf)
+{
+    pfx_loc* h = bound(pf);
+    if (!h) return;
+    pfx_loc_destroy(h);
+    memset(stash_of(pf), 0, sizeof(LocStash));
+}

@@ -1,0 +1,418 @@
+// pf_loc_kernels.h -- HIP kernels of the particleFilterLoc hot path (gfx950, wave64).
+//
+// One deposit (particleFilter.c:178-191) is three launches on the filter's stream, no host sync:
+//   k_loc_stream   VIO motion (pfMeasurement.c:24-49) + range gate (:108-125) + weight/pose sums
+//                  (pfResample.c:41-50, particleFilter.c:263-273) in ONE pass over the SoA arrays;
+//                  per-tile partial sums by wave shuffles + LDS.                       [HBM-bound]
+//   k_loc_decide   one workgroup: tile prefix (f64), ESS / respawn test, bandwidth, rStart (Philox),
+//                  first-offspring index of every tile (pfResample.c:51-68).           [tiny]
+//   k_loc_resample systematic resampling (pfResample.c:70-76): each workgroup rebuilds its tile's
+//                  CDF in LDS, binary-searches the ancestors of its contiguous offspring range,
+//                  gathers, jitters (pfInit.c:68-79), respawns (pfInit.c:56-66) and writes the
+//                  other ping-pong buffer; exits at once on a normalise-only step.      [HBM-bound]
+// The normalisation of a non-resampling step (pfResample.c:80-82, w *= N/s) is not a pass: the factor
+// is kept in the control block and multiplied in by the next reader of w (same product, same rounding).
+#pragma once
+
+#include "pf_common.h"
+
+namespace pf {
+
+struct LocBufs { float* a[2][5]; };     // [ping-pong][w,x,y,z,theta], each padded to a whole tile
+
+struct LocCtl {
+    int cur;            // buffer holding the current particles
+    int src, dst;       // chosen by k_loc_decide for k_loc_resample
+    int branch;         // 0 normalise-only, 1 resampled (or freshly spawned)
+    int numSpawn;
+    float wscale;       // pending factor on the stored weights
+    float htheta;
+    float s, ss, csum, ssum, ess, m;    // the reference's float totals (diagnostics / pfx_loc_last_stats)
+    double S;           // total weight, f64
+    double rStart, rStep;
+    double pose[6];     // sum w, w*x, w*y, w*z, w*cos, w*sin of the current particles
+    long long nDecisions;   // deposits decided so far (index into the branch log)
+};
+
+constexpr int kBranchLogSize = 65536;
+
+struct Motion { float dx, dy, dz, stdXyz, stdTheta; };
+struct Gate { float bx, by, bz, range, thresh, minWeight; };
+
+constexpr int kSumsPerTile = 8;     // s ss c sn wx wy wz (pad)
+constexpr int kRsPerTile = 8;       // x y z c sn count (pad)
+
+// ------------------------------------------------------------------ streaming pass
+template <bool MOTION, bool GATE>
+__global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const LocCtl* __restrict__ ctl,
+                                                        double* __restrict__ tileSums, long long n,
+                                                        RngKey key, Motion mo, Gate ga)
+{
+    __shared__ double red[4 * 7];
+    const int cur = ctl->cur;
+    const float wscale = ctl->wscale;
+    float* __restrict__ pw = bufs.a[cur][0];
+    float* __restrict__ px = bufs.a[cur][1];
+    float* __restrict__ py = bufs.a[cur][2];
+    float* __restrict__ pz = bufs.a[cur][3];
+    float* __restrict__ pt = bufs.a[cur][4];
+
+    const long long base = (long long)blockIdx.x * kTile + (long long)threadIdx.x * kPerThread;
+    const float4 w4 = *reinterpret_cast<const float4*>(pw + base);
+    const float4 x4 = *reinterpret_cast<const float4*>(px + base);
+    const float4 y4 = *reinterpret_cast<const float4*>(py + base);
+    const float4 z4 = *reinterpret_cast<const float4*>(pz + base);
+    const float4 t4 = *reinterpret_cast<const float4*>(pt + base);
+    float w[4] = { w4.x, w4.y, w4.z, w4.w }, x[4] = { x4.x, x4.y, x4.z, x4.w }, y[4] = { y4.x, y4.y, y4.z, y4.w };
+    float z[4] = { z4.x, z4.y, z4.z, z4.w }, th[4] = { t4.x, t4.y, t4.z, t4.w };
+
+    double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    bool thetaChanged = false;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        const long long i = base + k;
+        float wi = (i < n) ? w[k] * wscale : 0.0f;      // pad lanes never carry weight
+        float thi = th[k];
+        if (MOTION) {
+            // pfMeasurement.c:36-47
+            float s0, c0;
+            sincosf(thi, &s0, &c0);
+            const float pDx = mo.dx * c0 - mo.dy * s0;
+            const float pDy = mo.dx * s0 + mo.dy * c0;
+            const u32x4 r = rng_block(key, P_VIO, (uint64_t)i, 0);
+            float rx, ry, rz, rth;
+            normal2(r.a, r.b, rx, ry);
+            normal2(r.c, r.d, rz, rth);
+            x[k] += pDx + mo.stdXyz * rx;
+            y[k] += pDy + mo.stdXyz * ry;
+            z[k] += mo.dz + mo.stdXyz * rz;
+            thi = wrap_two_pi(thi + mo.stdTheta * rth);
+        } else {
+            // zero motion leaves x,y,z untouched and theta = fmodf(theta, 2pi): a no-op unless |theta| >= 2pi
+            const float t2 = wrap_two_pi(thi);
+            thetaChanged |= (t2 != thi);
+            thi = t2;
+        }
+        th[k] = thi;
+        if (GATE) {
+            // pfMeasurement.c:118-123
+            const float dx = x[k] - ga.bx, dy = y[k] - ga.by, dz = z[k] - ga.bz;
+            const float pRange = sqrtf(dx * dx + dy * dy + dz * dz);
+            if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
+        }
+        w[k] = wi;
+        // pfResample.c:44-48 and particleFilter.c:266-272: float products, added in double
+        float sn, cs;
+        sincosf(thi, &sn, &cs);
+        acc[0] += wi;
+        acc[1] += wi * wi;
+        acc[2] += wi * cs;
+        acc[3] += wi * sn;
+        acc[4] += wi * x[k];
+        acc[5] += wi * y[k];
+        acc[6] += wi * z[k];
+    }
+
+    *reinterpret_cast<float4*>(pw + base) = make_float4(w[0], w[1], w[2], w[3]);
+    if (MOTION) {
+        *reinterpret_cast<float4*>(px + base) = make_float4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<float4*>(py + base) = make_float4(y[0], y[1], y[2], y[3]);
+        *reinterpret_cast<float4*>(pz + base) = make_float4(z[0], z[1], z[2], z[3]);
+        *reinterpret_cast<float4*>(pt + base) = make_float4(th[0], th[1], th[2], th[3]);
+    } else if (thetaChanged) {
+        *reinterpret_cast<float4*>(pt + base) = make_float4(th[0], th[1], th[2], th[3]);
+    }
+
+    block_sum<7>(acc, red);
+    if (threadIdx.x == 0) {
+        double* o = tileSums + (size_t)blockIdx.x * kSumsPerTile;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[k] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------ decision (one workgroup)
+constexpr int kDecideThreads = 1024;
+
+__device__ __forceinline__ double block1024_sum(double v, double* lds16)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += lds16[k];
+    return t;       // every thread gets the same total
+}
+
+// force: -1 follow the reference's test, 0 never resample, 1 always resample (worst-case traffic runs)
+__global__ __launch_bounds__(kDecideThreads) void k_loc_decide(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
+                                                              double* __restrict__ tileBase, long long* __restrict__ firstOut,
+                                                              int numTiles, long long n, float range, RngKey key, int force,
+                                                              unsigned char* __restrict__ branchLog)
+{
+    __shared__ double lds16[16];
+    __shared__ double shS, shStart, shStep;
+    __shared__ int shBranch;
+
+    const int tid = threadIdx.x;
+    const int chunk = (numTiles + kDecideThreads - 1) / kDecideThreads;
+    const int begin = min(tid * chunk, numTiles), end = min(begin + chunk, numTiles);
+
+    double loc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    for (int t = begin; t < end; ++t) {
+        const double* p = tileSums + (size_t)t * kSumsPerTile;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) loc[k] += p[k];
+    }
+    // exclusive scan of the per-thread weight totals (wave scan + 16 wave totals)
+    double inc = loc[0];
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double up = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += up;
+    }
+    if (lane == 63) lds16[wave] = inc;
+    __syncthreads();
+    double pre = 0.0;
+    for (int k = 0; k < wave; ++k) pre += lds16[k];
+    double run = pre + (inc - loc[0]);
+    for (int t = begin; t < end; ++t) {
+        tileBase[t] = run;
+        run += tileSums[(size_t)t * kSumsPerTile];
+    }
+    if (end == numTiles && begin < end) { tileBase[numTiles] = run; shS = run; }
+
+    double tot[7];
+    tot[0] = 0.0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) tot[k] = block1024_sum(loc[k], lds16);
+    __syncthreads();
+
+    if (tid == 0) {
+        const double S = shS;
+        const int cur = ctl->cur;
+        // pfResample.c:51-58 on the float-rounded totals
+        const float s = (float)S, ss = (float)tot[1];
+        float csum = (float)tot[2], ssum = (float)tot[3];
+        const float ess = s * s / ss;
+        const float invN = 1.0f / (float)n;
+        int numSpawn = 0;
+        if (s * invN < kWeightSpawnThresh && range < kRadiusSpawnThresh) numSpawn = (int)lroundf((float)n * kPctSpawn);
+        bool resample = (ess * invN < kResampleThresh) || numSpawn > 0;
+        if (force >= 0) resample = force != 0;
+        ctl->s = s; ctl->ss = ss; ctl->csum = csum; ctl->ssum = ssum; ctl->ess = ess; ctl->S = S;
+        ctl->numSpawn = numSpawn;
+        if (resample) {
+            // pfResample.c:60-68
+            csum /= s;
+            ssum /= s;
+            float h = csum * csum + ssum * ssum;
+            h = h > 1e-10f ? h : 1e-10f;
+            h = h < 1.0f - 1e-10f ? h : 1.0f - 1e-10f;
+            h = sqrtf(-logf(h) / ess);
+            const double rStep = S / (double)n;
+            const double rStart = (double)uniform01(rng_block(key, P_RSTART, 0, 0).a) * rStep;
+            ctl->htheta = h; ctl->rStep = rStep; ctl->rStart = rStart;
+            ctl->src = cur; ctl->dst = cur ^ 1; ctl->cur = cur ^ 1;
+            ctl->wscale = 1.0f; ctl->m = 0.0f; ctl->branch = 1;
+            shStart = rStart; shStep = rStep;
+        } else {
+            // pfResample.c:80-82, deferred: the next reader multiplies w by m
+            const float m = (float)n / s;
+            ctl->wscale = m; ctl->m = m; ctl->branch = 0; ctl->htheta = 0.0f;
+            ctl->pose[0] = S; ctl->pose[1] = tot[4]; ctl->pose[2] = tot[5]; ctl->pose[3] = tot[6];
+            ctl->pose[4] = tot[2]; ctl->pose[5] = tot[3];
+        }
+        shBranch = resample ? 1 : 0;
+        const long long k = ctl->nDecisions;
+        branchLog[k % kBranchLogSize] = resample ? 1 : 0;
+        ctl->nDecisions = k + 1;
+    }
+    __syncthreads();
+    if (!shBranch) return;
+
+    // first offspring of every tile: the number of i in [0,n) with rStart + rStep*i < tileBase[t]
+    const double rStart = shStart, rStep = shStep;
+    const bool sane = (rStep > 0.0) && (rStep < 1e300);
+    for (int t = begin; t < end; ++t) {
+        long long f = 0;
+        if (t > 0 && sane) {
+            const double b = tileBase[t];
+            const double q = ceil((b - rStart) / rStep);
+            f = q < 0.0 ? 0 : (q > (double)n ? n : (long long)q);
+            for (int it = 0; it < 8 && f > 0 && !(rStart + rStep * (double)(f - 1) < b); ++it) --f;
+            for (int it = 0; it < 8 && f < n && (rStart + rStep * (double)f < b); ++it) ++f;
+        }
+        firstOut[t] = f;
+    }
+    if (tid == 0) firstOut[numTiles] = n;
+}
+
+// ------------------------------------------------------------------ resample
+template <bool RECORD>
+__global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const LocCtl* __restrict__ ctl,
+                                                          const double* __restrict__ tileBase,
+                                                          const long long* __restrict__ firstOut,
+                                                          double* __restrict__ rsPart, int* __restrict__ ancOut,
+                                                          long long n, RngKey key, float bx, float by, float bz,
+                                                          float range, float stdRange)
+{
+    if (ctl->branch != 1) return;           // normalise-only step: nothing to do (wave-uniform exit)
+
+    __shared__ double cdf[kTile];
+    __shared__ double red[4 * 6];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const long long i0 = firstOut[t], i1 = firstOut[t + 1];
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+
+    if (i0 < i1) {
+        const int src = ctl->src, dst = ctl->dst;
+        const float* __restrict__ sw = bufs.a[src][0];
+        const float* __restrict__ sx = bufs.a[src][1];
+        const float* __restrict__ sy = bufs.a[src][2];
+        const float* __restrict__ sz = bufs.a[src][3];
+        const float* __restrict__ st = bufs.a[src][4];
+        float* __restrict__ dw = bufs.a[dst][0];
+        float* __restrict__ dx = bufs.a[dst][1];
+        float* __restrict__ dy = bufs.a[dst][2];
+        float* __restrict__ dz = bufs.a[dst][3];
+        float* __restrict__ dt = bufs.a[dst][4];
+
+        // this tile's CDF, rebuilt from the weights (pfResample.c:45,49 in double): base + inclusive scan
+        const long long tbase = (long long)t * kTile;
+        const float4 w4 = *reinterpret_cast<const float4*>(sw + tbase + tid * kPerThread);
+        const double a0 = w4.x, a1 = a0 + w4.y, a2 = a1 + w4.z, a3 = a2 + w4.w;
+        double total;
+        const double incl = block_inclusive_scan(a3, red, total);
+        const double off = tileBase[t] + (incl - a3);
+        cdf[tid * 4 + 0] = off + a0;
+        cdf[tid * 4 + 1] = off + a1;
+        cdf[tid * 4 + 2] = off + a2;
+        cdf[tid * 4 + 3] = off + a3;
+        __syncthreads();
+
+        const long long rem = n - tbase;
+        const int nValid = rem < kTile ? (int)rem : kTile;
+        const double rStart = ctl->rStart, rStep = ctl->rStep;
+        const float hTheta = ctl->htheta;
+        const int numSpawn = ctl->numSpawn;
+
+        for (long long i = i0 + tid; i < i1; i += kThreads) {
+            const double u = rStart + rStep * (double)i;        // pfResample.c:71
+            const int j = upper_bound_clamped<double>(cdf, nValid, u);
+            const long long a = tbase + j;
+            float x, y, z, th;
+            if (i < numSpawn) {
+                spawn_from_range(key, (uint64_t)i, bx, by, bz, range, stdRange, x, y, z, th);   // pfResample.c:75-76
+            } else {
+                spawn_from_other(key, (uint64_t)i, sx[a], sy[a], sz[a], st[a], kHxyz, hTheta, x, y, z, th);
+            }
+            dw[i] = 1.0f; dx[i] = x; dy[i] = y; dz[i] = z; dt[i] = th;
+            if (RECORD) ancOut[i] = (int)a;
+            float sn, cs;
+            sincosf(th, &sn, &cs);
+            acc[0] += x; acc[1] += y; acc[2] += z; acc[3] += cs; acc[4] += sn; acc[5] += 1.0;
+        }
+        __syncthreads();
+    }
+    block_sum<6>(acc, red);
+    if (tid == 0) {
+        double* o = rsPart + (size_t)t * kRsPerTile;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------ initial spawn (pfInit.c:20-25)
+__global__ __launch_bounds__(kThreads) void k_loc_spawn(LocBufs bufs, LocCtl* __restrict__ ctl, double* __restrict__ rsPart,
+                                                       long long n, RngKey key, float bx, float by, float bz,
+                                                       float range, float stdRange)
+{
+    __shared__ double red[4 * 6];
+    const int cur = ctl->cur;
+    float* __restrict__ pw = bufs.a[cur][0];
+    float* __restrict__ px = bufs.a[cur][1];
+    float* __restrict__ py = bufs.a[cur][2];
+    float* __restrict__ pz = bufs.a[cur][3];
+    float* __restrict__ pt = bufs.a[cur][4];
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    const long long tbase = (long long)blockIdx.x * kTile;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        const long long i = tbase + k * kThreads + threadIdx.x;
+        if (i < n) {
+            float x, y, z, th;
+            spawn_from_range(key, (uint64_t)i, bx, by, bz, range, stdRange, x, y, z, th);
+            pw[i] = 1.0f; px[i] = x; py[i] = y; pz[i] = z; pt[i] = th;
+            float sn, cs;
+            sincosf(th, &sn, &cs);
+            acc[0] += x; acc[1] += y; acc[2] += z; acc[3] += cs; acc[4] += sn; acc[5] += 1.0;
+        } else {
+            pw[i] = 0.0f; px[i] = 0.0f; py[i] = 0.0f; pz[i] = 0.0f; pt[i] = 0.0f;
+        }
+    }
+    block_sum<6>(acc, red);
+    if (threadIdx.x == 0) {
+        double* o = rsPart + (size_t)blockIdx.x * kRsPerTile;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------ small control kernels
+__global__ void k_loc_set_ctl(LocCtl* ctl, int cur, int branch, float wscale, int keepCur)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (!keepCur) ctl->cur = cur;
+        ctl->branch = branch;
+        ctl->wscale = wscale;
+    }
+}
+
+// Sum the per-tile pose partials of the last writer of the particles into ctl->pose (one workgroup).
+// After a normalise-only step k_loc_decide has already done this from the streaming pass.
+__global__ __launch_bounds__(kThreads) void k_loc_pose(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
+                                                      const double* __restrict__ rsPart, int numTiles, long long n)
+{
+    __shared__ double red[4 * 6];
+    const int branch = ctl->branch;
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int t = threadIdx.x; t < numTiles; t += kThreads) {
+        if (branch == 1) {
+            const double* p = rsPart + (size_t)t * kRsPerTile;
+            acc[0] += p[5]; acc[1] += p[0]; acc[2] += p[1]; acc[3] += p[2]; acc[4] += p[3]; acc[5] += p[4];
+        } else {
+            const double* p = tileSums + (size_t)t * kSumsPerTile;
+            acc[0] += p[0]; acc[1] += p[4]; acc[2] += p[5]; acc[3] += p[6]; acc[4] += p[2]; acc[5] += p[3];
+        }
+    }
+    block_sum<6>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ctl->pose[k] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------ index selection on a caller CDF
+// anc[i] = first j with rStart + rStep*i < cdf[j], else n-1 (pfResample.c:70-72).  T = float reproduces the
+// reference's float expression exactly (no fused multiply-add: -ffp-contract=off); T = double is the
+// production rule.  Same upper_bound_clamped as k_loc_resample, on global memory.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_resample_indices(const T* __restrict__ cdf, long long n, T rStart, T rStep,
+                                                              int* __restrict__ anc)
+{
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const T u = rStart + rStep * (T)i;
+    long long lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (u < cdf[mid]) hi = mid; else lo = mid + 1;
+    }
+    anc[i] = (int)lo;
+}
+
+}  // namespace pf

@@ -1,0 +1,265 @@
+"""Host-side mirror of the reference's Python module ``particlefilter``
+(particlefilter/cython/particlefilter_wrapper.pyx:27-49): class ``ParticleFilterLoc`` with
+``depositVio / depositRange / depositRssi / getTagLoc`` and the module function ``setSeed``,
+same argument meaning and return shapes -- over libparticlefilter.so (HIP kernels) instead of
+the C sources compiled into the extension.
+
+Two classes share that interface:
+
+* ``ParticleFilterLoc``        -- drop-in: owns a reference-layout ``particleFilterLoc_t`` (400 056 B)
+  and calls the reference's own entry points ``particleFilterLoc_*`` exactly as the Cython wrapper
+  does.  N is PF_N_TAG_LOC (10 000) unless the environment variable PF_HIP_N_TAG_LOC overrides it.
+* ``DeviceParticleFilterLoc`` -- the pfx_* extension: particle count, device, seed chosen at run
+  time; adds state upload/download and the single stages of a step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import PfxError, check
+
+PF_N_TAG_LOC = 10000
+SIZEOF_LOC = 400056          # sizeof(particleFilterLoc_t), include/particleFilter.h
+
+_seed: Optional[int] = None
+
+
+def setSeed(seed) -> None:
+    """particlefilter_wrapper.pyx:48-49 -> particleFilterSeed_set (particleFilter.c:26-30)."""
+    global _seed
+    _seed = int(seed) & 0xFFFFFFFF
+    _lib.lib().particleFilterSeed_set(_seed)
+
+
+def _pose_tuple(ok, t, x, y, z, th):
+    return (int(ok), t.value, np.float32(x.value), np.float32(y.value), np.float32(z.value), np.float32(th.value))
+
+
+class ParticleFilterLoc:
+    """The reference wrapper's class, over the reference-layout C entry points."""
+
+    def __init__(self) -> None:
+        self._L = _lib.lib()
+        self._buf = C.create_string_buffer(SIZEOF_LOC)      # cdef particleFilterLoc_t pf (wrapper :28)
+        self._p = C.cast(self._buf, C.c_void_p)
+        self._L.particleFilterLoc_init(self._p)              # __cinit__ (wrapper :30-31)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_p", None) is not None:
+                self._L.pfx_loc_release(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+    def depositVio(self, t, x, y, z, dist) -> None:
+        self._L.particleFilterLoc_depositVio(self._p, t, x, y, z, dist)
+
+    def depositRange(self, bx, by, bz, range, stdRange) -> None:      # noqa: A002 (name kept from the wrapper)
+        self._L.particleFilterLoc_depositRange(self._p, bx, by, bz, range, stdRange)
+
+    def depositRssi(self, bx, by, bz, rssi) -> None:
+        self._L.particleFilterLoc_depositRssi(self._p, bx, by, bz, int(rssi))
+
+    def getTagLoc(self) -> Tuple[int, float, np.float32, np.float32, np.float32, np.float32]:
+        t = C.c_double()
+        x, y, z, th = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        ok = self._L.particleFilterLoc_getTagLoc(self._p, C.byref(t), C.byref(x), C.byref(y), C.byref(z), C.byref(th))
+        return _pose_tuple(ok, t, x, y, z, th)
+
+    # -- additions
+    def device_filter(self) -> "DeviceParticleFilterLoc":
+        h = self._L.pfx_loc_of(self._p)
+        if not h:
+            raise PfxError("struct is not bound to a device filter")
+        return DeviceParticleFilterLoc._borrow(h)
+
+    def particles(self) -> np.ndarray:
+        """(PF_N_TAG_LOC, 5) float32 copy of pTag[] (w, x, y, z, theta), refreshed from HBM."""
+        check(self._L.pfx_loc_sync_host(self._p), "pfx_loc_sync_host")
+        return np.frombuffer(self._buf, dtype=np.float32, count=PF_N_TAG_LOC * 5).reshape(PF_N_TAG_LOC, 5).copy()
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceParticleFilterLoc:
+    """particleFilterLoc with runtime N on a chosen GPU (pfx_loc_*, include/pfx.h)."""
+
+    def __init__(self, n: int = PF_N_TAG_LOC, seed: Optional[int] = None, stream_id: int = 0, device: int = 0):
+        self._L = _lib.lib()
+        if seed is None:
+            seed = _seed if _seed is not None else 0
+        self._h = self._L.pfx_loc_create(int(n), int(seed) & 0xFFFFFFFF, int(stream_id), int(device))
+        if not self._h:
+            raise PfxError(f"pfx_loc_create: {_lib.last_error()}")
+        self._own = True
+        self.n = int(n)
+
+    @classmethod
+    def _borrow(cls, handle) -> "DeviceParticleFilterLoc":
+        self = cls.__new__(cls)
+        self._L = _lib.lib()
+        self._h = handle
+        self._own = False
+        self.n = int(self._L.pfx_loc_n(handle))
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None) and self._own:
+            self._L.pfx_loc_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the wrapper interface
+    def depositVio(self, t, x, y, z, dist) -> None:
+        self._L.pfx_loc_deposit_vio(self._h, t, x, y, z, dist)
+
+    def depositRange(self, bx, by, bz, range, stdRange) -> None:      # noqa: A002
+        check(self._L.pfx_loc_deposit_range(self._h, bx, by, bz, range, stdRange), "pfx_loc_deposit_range")
+
+    def depositRssi(self, bx, by, bz, rssi) -> None:
+        check(self._L.pfx_loc_deposit_rssi(self._h, bx, by, bz, int(rssi)), "pfx_loc_deposit_rssi")
+
+    def getTagLoc(self):
+        t = C.c_double()
+        x, y, z, th = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        ok = check(self._L.pfx_loc_get_tag_loc(self._h, C.byref(t), C.byref(x), C.byref(y), C.byref(z), C.byref(th)),
+                   "pfx_loc_get_tag_loc")
+        return _pose_tuple(ok, t, x, y, z, th)
+
+    # -- control
+    def reset(self, seed: int, stream_id: int = 0):
+        check(self._L.pfx_loc_reset(self._h, int(seed) & 0xFFFFFFFF, int(stream_id)), "pfx_loc_reset")
+
+    def sync(self):
+        check(self._L.pfx_loc_sync(self._h), "pfx_loc_sync")
+
+    def set_stream(self, hip_stream: int):
+        check(self._L.pfx_loc_set_stream(self._h, C.c_void_p(hip_stream)), "pfx_loc_set_stream")
+
+    def set_force_branch(self, force: int):
+        check(self._L.pfx_loc_set_force_branch(self._h, int(force)), "pfx_loc_set_force_branch")
+
+    @property
+    def initialized(self) -> bool:
+        return bool(self._L.pfx_loc_initialized(self._h))
+
+    @property
+    def seed(self) -> int:
+        return int(self._L.pfx_loc_seed(self._h))
+
+    @property
+    def stream_id(self) -> int:
+        return int(self._L.pfx_loc_stream_id(self._h))
+
+    @property
+    def epoch(self) -> int:
+        return int(self._L.pfx_loc_epoch(self._h))
+
+    @epoch.setter
+    def epoch(self, e: int):
+        self._L.pfx_loc_set_epoch(self._h, int(e))
+
+    # -- state
+    def upload(self, w, x, y, z, theta, initialized: bool = True):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (w, x, y, z, theta)]
+        for a in arrs:
+            if a.shape != (self.n,):
+                raise ValueError(f"expected {self.n} particles, got {a.shape}")
+        check(self._L.pfx_loc_upload(self._h, *[_fptr(a) for a in arrs], self.n, int(initialized)), "pfx_loc_upload")
+
+    def download(self):
+        out = [np.empty(self.n, dtype=np.float32) for _ in range(5)]
+        check(self._L.pfx_loc_download(self._h, *[_fptr(a) for a in out], self.n), "pfx_loc_download")
+        return tuple(out)
+
+    def device_arrays(self):
+        ptrs = (C.c_void_p * 5)()
+        ws = C.c_float()
+        check(self._L.pfx_loc_device_arrays(self._h, ptrs, C.byref(ws)), "pfx_loc_device_arrays")
+        return [int(p) for p in ptrs], float(ws.value)
+
+    # -- the stages of a step
+    def apply_vio(self, dt, dx, dy, dz, ddist):
+        check(self._L.pfx_loc_apply_vio(self._h, dt, dx, dy, dz, ddist), "pfx_loc_apply_vio")
+
+    def apply_range(self, bx, by, bz, range, stdRange):               # noqa: A002
+        check(self._L.pfx_loc_apply_range(self._h, bx, by, bz, range, stdRange), "pfx_loc_apply_range")
+
+    def resample(self, bx, by, bz, range, stdRange):                  # noqa: A002
+        check(self._L.pfx_loc_resample(self._h, bx, by, bz, range, stdRange), "pfx_loc_resample")
+
+    def spawn_all(self, bx, by, bz, range, stdRange):                 # noqa: A002
+        check(self._L.pfx_loc_spawn_all(self._h, bx, by, bz, range, stdRange), "pfx_loc_spawn_all")
+
+    def last_stats(self) -> dict:
+        buf = (C.c_double * 12)()
+        check(self._L.pfx_loc_last_stats(self._h, buf), "pfx_loc_last_stats")
+        keys = ["branch", "numSpawn", "s", "ss", "csum", "ssum", "ess", "htheta", "rStart", "rStep", "m", "S"]
+        return dict(zip(keys, list(buf)))
+
+    def record_ancestors(self, enable: bool = True):
+        check(self._L.pfx_loc_record_ancestors(self._h, int(enable)), "pfx_loc_record_ancestors")
+
+    def last_ancestors(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.int32)
+        check(self._L.pfx_loc_last_ancestors(self._h, _fptr(out), self.n), "pfx_loc_last_ancestors")
+        return out
+
+    # -- kernel timing
+    def profile_begin(self, max_records: int = 4096):
+        check(self._L.pfx_loc_profile_begin(self._h, int(max_records)), "pfx_loc_profile_begin")
+
+    KINDS = ["stream", "decide", "resample", "spawn", "pose", "stream_static"]
+
+    def profile_records(self, cap: int = 1 << 16):
+        """(kind, ms) per recorded launch, in launch order; kind indexes KINDS."""
+        kind = np.empty(cap, dtype=np.int32)
+        ms = np.empty(cap, dtype=np.float32)
+        k = check(self._L.pfx_loc_profile_records(self._h, _fptr(kind), _fptr(ms), cap), "pfx_loc_profile_records")
+        return kind[:k].copy(), ms[:k].copy()
+
+    def profile_read(self) -> dict:
+        ms = (C.c_double * 6)()
+        cnt = (C.c_int64 * 6)()
+        check(self._L.pfx_loc_profile_read(self._h, ms, cnt), "pfx_loc_profile_read")
+        return {k: {"ms": ms[i], "launches": int(cnt[i])} for i, k in enumerate(self.KINDS)}
+
+    def branch_log(self, cap: int = 65536):
+        """branches of the most recent deposits (1 resampled, 0 normalised) and the total count"""
+        out = np.empty(cap, dtype=np.uint8)
+        total = C.c_int64()
+        k = check(self._L.pfx_loc_branch_log(self._h, _fptr(out), cap, C.byref(total)), "pfx_loc_branch_log")
+        return out[:k].copy(), int(total.value)
+
+
+def resample_indices_f32(cdf, r_start, r_step, device: int = 0) -> np.ndarray:
+    """anc[i] = first j with r_start + r_step*i < cdf[j] (float32, pfResample.c:70-72), on the GPU."""
+    cdf = np.ascontiguousarray(cdf, dtype=np.float32)
+    out = np.empty(cdf.shape[0], dtype=np.int32)
+    check(_lib.lib().pfx_resample_indices_f32(_fptr(cdf), cdf.shape[0], np.float32(r_start), np.float32(r_step),
+                                              _fptr(out), device), "pfx_resample_indices_f32")
+    return out
+
+
+def resample_indices_f64(cdf, r_start, r_step, device: int = 0) -> np.ndarray:
+    cdf = np.ascontiguousarray(cdf, dtype=np.float64)
+    out = np.empty(cdf.shape[0], dtype=np.int32)
+    check(_lib.lib().pfx_resample_indices_f64(_fptr(cdf), cdf.shape[0], float(r_start), float(r_step),
+                                              _fptr(out), device), "pfx_resample_indices_f64")
+    return out
+
+
+def device_count() -> int:
+    return int(_lib.lib().pfx_device_count())

@@ -1,0 +1,384 @@
+"""GPU parity tests of the particleFilterLoc hot path: HIP kernels (through the C-ABI) vs the CPU oracle.
+
+Bars (BASELINE.json north_star):
+  * integer / index / predicate work is bit-exact: Philox words and the uniform conversion (theta of a
+    spawned particle), the 3-sigma range gate on identical positions, resampling indices on an identical
+    CDF and uniform draw (float32 expression of pfResample.c:71, and the float64 production rule);
+  * anything behind a transcendental (Box-Muller, sin/cos of the heading, asinf/atan2f) is float32 within
+    TOL_ABS = 2e-6 absolute on metre/radian-scale values (device libm vs glibc differ in the last ulp);
+  * weight sums are accumulated in float64 on both sides but in a different association:
+    relative 1e-12.
+The oracle runs in Philox mode with the f64 accumulation rule (ORA_RNG_PHILOX, ORA_ACC_F64); its
+restatement of the reference is pinned separately by the CPU tests.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import _synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_ABS = 2e-6
+SEED = 123456789
+
+
+@pytest.fixture(scope="module")
+def pfm():
+    from slam3d_amd import particlefilter as m
+    if m.device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests must run on an MI355X box")
+    return m
+
+
+def _pair(pfm, ora, n, seed=SEED, stream=0):
+    g = pfm.DeviceParticleFilterLoc(n, seed=seed, stream_id=stream)
+    o = ora.OracleLoc(n, rng_mode=ora.RNG_PHILOX, seed=seed, acc=ora.ACC_F64)
+    return g, o
+
+
+def _load(g, o, p, epoch=0):
+    cols = [np.ascontiguousarray(p[:, k]) for k in range(5)]
+    g.upload(*cols, initialized=True)
+    o.set_particles(*cols)
+    o.set_initialized(1)
+    g.epoch = epoch
+    o.epoch = epoch
+
+
+# ------------------------------------------------------------------ spawn: Philox + uniform conversion
+@pytest.mark.parametrize("n", [1, 1000, 1023, 1024, 1025, 10000, 100003])
+@pytest.mark.parametrize("beacon", [(1.0, 2.0, 0.5, 5.0, 0.1), (0.0, 0.0, 0.0, 0.2, 0.5)])
+def test_spawn_all(pfm, ora, n, beacon):
+    g, o = _pair(pfm, ora, n)
+    g.epoch = o.epoch = 7
+    g.spawn_all(*beacon)
+    o.spawn_all(*beacon)
+    gw, gx, gy, gz, gt = g.download()
+    ow, ox, oy, oz, ot = o.arrays()
+    assert np.array_equal(gw, ow) and np.all(gw == 1.0)
+    assert np.array_equal(gt, ot)                       # theta = uniform * 2pi: no transcendental -> bit-exact
+    for a, b in ((gx, ox), (gy, oy), (gz, oz)):
+        assert np.abs(a - b).max() <= TOL_ABS
+    if beacon[3] < 3 * beacon[4]:
+        # radius retries were needed for some particles (range - 3 sigma < 0): all radii are >= 0
+        r = np.sqrt((gx - beacon[0]) ** 2 + (gy - beacon[1]) ** 2 + (gz - beacon[2]) ** 2)
+        assert r.max() <= beacon[3] + 3 * beacon[4] + 1e-5
+
+
+# ------------------------------------------------------------------ range gate: bit-exact weights
+RANGE_CASES = [c for c in _synth.LOC_FUNC_CASES if c["ops"] == ["range"]]
+
+
+@pytest.mark.parametrize("case", RANGE_CASES, ids=[c["name"] for c in RANGE_CASES])
+@pytest.mark.parametrize("n", [10000, 65537])
+def test_apply_range_bit_exact(pfm, ora, case, n):
+    g, o = _pair(pfm, ora, n)
+    p = _synth.loc_particles(n, case["pseed"], case["kind"])
+    _load(g, o, p)
+    g.apply_range(*case["beacon"])
+    o.apply_range(*case["beacon"])
+    gw, gx, gy, gz, gt = g.download()
+    ow = o.arrays()[0]
+    assert np.array_equal(gw, ow)
+    assert np.array_equal(gx, p[:, 1]) and np.array_equal(gt, p[:, 4])      # positions untouched
+    assert 0 < int(np.sum(gw != p[:, 0])) < n                                 # the gate did discriminate
+
+
+def test_apply_range_idempotent_when_nothing_gated(pfm, ora):
+    n = 5000
+    g, o = _pair(pfm, ora, n)
+    p = _synth.loc_particles(n, 3, "mixed")
+    _load(g, o, p)
+    g.apply_range(1.0, 2.0, 0.5, 5.0, 1000.0)      # 3 sigma = 3 km: nothing is outside
+    g.apply_range(1.0, 2.0, 0.5, 5.0, 1000.0)
+    assert np.array_equal(g.download()[0], p[:, 0])
+
+
+# ------------------------------------------------------------------ VIO motion
+@pytest.mark.parametrize("vio", [(0.11, 0.04, -0.03, 0.01, 0.051), (0.0, 0.0, 0.0, 0.0, 0.0), (2.0, 1.0, -2.0, 0.5, 3.0)])
+@pytest.mark.parametrize("n", [10000, 4097])
+def test_apply_vio(pfm, ora, vio, n):
+    g, o = _pair(pfm, ora, n)
+    p = _synth.loc_particles(n, 14, "mixed")
+    p[:5, 4] = [6.2831855, -6.2831855, 6.5, -7.0, 13.0]      # headings at / beyond +-2pi exercise the wrap
+    _load(g, o, p, epoch=3)
+    g.apply_vio(*vio)
+    o.apply_vio(*vio)
+    got = g.download()
+    exp = o.arrays()
+    assert np.array_equal(got[0], exp[0])
+    for k in range(1, 5):
+        d = np.abs(got[k] - exp[k])
+        if k == 4:
+            # a heading that lands within an ulp of +-2pi can wrap on one side only: compare on the circle
+            d = np.minimum(d, np.abs(d - 6.2831855))
+        assert d.max() <= TOL_ABS, k
+    assert np.all(np.abs(got[4]) < 6.2831855)
+
+
+# ------------------------------------------------------------------ resampling indices on a given CDF
+def _cdfs():
+    out = []
+    for n, seed, kind in ((10000, 1, "u"), (10000, 2, "two"), (100003, 3, "u"), (1 << 20, 4, "two"), (1000, 5, "deg")):
+        u = _synth.u01(seed, n)
+        if kind == "u":
+            w = (0.05 + u).astype(np.float32)
+        elif kind == "two":
+            w = np.where(u < 0.3, 1.0, 0.1).astype(np.float32)
+        else:
+            w = np.where(u < 0.01, 1.0, 0.0).astype(np.float32)
+            w[-1] = 1.0
+        out.append((f"{kind}{n}", w))
+    return out
+
+
+@pytest.mark.parametrize("name,w", _cdfs(), ids=[c[0] for c in _cdfs()])
+@pytest.mark.parametrize("ufrac", [0.0, 0.37, 0.999999, 1.0])
+def test_resample_indices_f32_bit_exact(pfm, ora, name, w, ufrac):
+    """Identical CDF + identical uniform draw -> identical ancestor indices (north_star), using the
+    reference's serial float32 CDF and its float32 expression rStart + rStep*i."""
+    n = w.shape[0]
+    cdf = np.cumsum(w, dtype=np.float32)            # serial float32 running sum == pfResample.c:45,49
+    s = cdf[-1]
+    r_step = np.float32(np.float32(1.0) / np.float32(n)) * s          # invN * s   (pfResample.c:53,67)
+    r_start = np.float32(ufrac) * r_step                              # uniform() * rStep (:68)
+    exp = ora.resample_indices_f32(cdf, r_start, r_step)
+    got = pfm.resample_indices_f32(cdf, r_start, r_step)
+    assert np.array_equal(got, exp)
+    assert got[-1] <= n - 1 and np.all(np.diff(got) >= 0)
+
+
+@pytest.mark.parametrize("name,w", _cdfs()[:4], ids=[c[0] for c in _cdfs()[:4]])
+def test_resample_indices_f64_bit_exact(pfm, ora, name, w):
+    n = w.shape[0]
+    cdf = np.cumsum(w.astype(np.float64))
+    r_step = cdf[-1] / n
+    for ufrac in (0.0, 0.5, 1.0):
+        exp = ora.resample_indices_f64(cdf, ufrac * r_step, r_step)
+        got = pfm.resample_indices_f64(cdf, ufrac * r_step, r_step)
+        assert np.array_equal(got, exp)
+
+
+# ------------------------------------------------------------------ the resample stage against the oracle
+RS_CASES = [c for c in _synth.LOC_FUNC_CASES if c["ops"] == ["resample"]]
+
+
+@pytest.mark.parametrize("case", RS_CASES, ids=[c["name"] for c in RS_CASES])
+@pytest.mark.parametrize("n", [10000, 30011])
+def test_resample_stage(pfm, ora, case, n):
+    g, o = _pair(pfm, ora, n)
+    p = _synth.loc_particles(n, case["pseed"], case["kind"])
+    _load(g, o, p, epoch=11)
+    g.record_ancestors(True)
+    g.resample(*case["beacon"])
+    o.resample(*case["beacon"])
+    gs, os_ = g.last_stats(), o.last_stats()
+    assert int(gs["branch"]) == int(os_["branch"])
+    assert int(gs["numSpawn"]) == int(os_["numSpawn"])
+    for k in ("s", "ss", "ess"):
+        assert gs[k] == pytest.approx(os_[k], rel=2e-6, abs=1e-6), k
+    for k in ("csum", "ssum"):
+        # sums of w*cos(theta), w*sin(theta): each term carries the 1-ulp difference between the device's and
+        # glibc's cosf/sinf (<= 1.2e-7 * w), and the terms cancel -- so the bound is relative to sum(w), not to
+        # the (possibly small) total
+        assert abs(gs[k] - os_[k]) <= 1e-7 * os_["s"] + 1e-6, k
+    got = g.download()
+    exp = o.arrays()
+    if int(os_["branch"]):
+        assert gs["rStep"] == pytest.approx(os_["rStep"], rel=1e-12)
+        assert gs["rStart"] == pytest.approx(os_["rStart"], rel=1e-12, abs=1e-300)
+        assert gs["htheta"] == pytest.approx(os_["htheta"], rel=1e-5)
+        anc_g, anc_o = g.last_ancestors(), o.last_ancestors()
+        # identical weights + identical uniform draw -> identical indices under the f64 rule.  The two f64 CDFs
+        # differ only in summation order (~1e-16 relative), so a differing index needs an offspring within
+        # that distance of a CDF step: allow at most one, and only to a neighbouring ancestor.
+        bad = np.nonzero(anc_g != anc_o)[0]
+        assert bad.size <= 1 and (bad.size == 0 or abs(int(anc_g[bad[0]]) - int(anc_o[bad[0]])) == 1)
+        ok = np.ones(n, dtype=bool)
+        ok[bad] = False
+        assert np.all(got[0] == 1.0)
+        for k in range(1, 5):
+            # jitter is hXyz = 0.1 (or htheta) times a Box-Muller normal: absolute error well under 2e-6;
+            # a heading within 1e-6 of +-2pi may wrap on one side only
+            d = np.abs(got[k] - exp[k])[ok]
+            if k == 4:
+                d = np.minimum(d, np.abs(d - 6.2831855))
+            assert d.max() <= 5e-6, k
+    else:
+        assert np.abs(got[0] - exp[0]).max() <= 1e-6 * max(1.0, float(np.abs(exp[0]).max()))
+        assert gs["m"] == pytest.approx(os_["m"], rel=1e-6)
+        for k in range(1, 5):
+            assert np.array_equal(got[k], exp[k])
+
+
+def test_systematic_resampling_properties_large(pfm):
+    """Size-independent properties at N = 4M (BASELINE config sizes are run by bench.py): ancestors are
+    sorted, every offspring count is floor or ceil of w_j / rStep, the population is conserved, w == 1."""
+    n = 1 << 22
+    g = pfm.DeviceParticleFilterLoc(n, seed=5)
+    u = _synth.u01(77, n)
+    w = np.where(u < 0.2, 1.0, 0.1).astype(np.float32)
+    z = np.zeros(n, dtype=np.float32)
+    g.upload(w, z, z, z, z)
+    g.record_ancestors(True)
+    g.set_force_branch(1)
+    g.resample(0.0, 0.0, 0.0, 10.0, 0.1)
+    st = g.last_stats()
+    assert int(st["branch"]) == 1 and int(st["numSpawn"]) == 0
+    assert st["S"] == pytest.approx(float(w.astype(np.float64).sum()), rel=1e-13)
+    anc = g.last_ancestors()
+    assert anc.min() >= 0 and anc.max() < n and np.all(np.diff(anc) >= 0)
+    counts = np.bincount(anc, minlength=n)
+    assert counts.sum() == n
+    expect = w.astype(np.float64) / st["rStep"]
+    assert np.all(counts >= np.floor(expect) - 1e-9) and np.all(counts <= np.ceil(expect) + 1e-9)
+    gw = g.download()[0]
+    assert np.all(gw == 1.0)
+
+
+# ------------------------------------------------------------------ pose reduction
+@pytest.mark.parametrize("n", [1, 777, 10000, 250001])
+def test_get_tag_loc(pfm, ora, n):
+    g, o = _pair(pfm, ora, n)
+    p = _synth.loc_particles(n, 31, "mixed")
+    _load(g, o, p)
+    for f in (g, o):
+        f.depositVio(12.5, 0.125, 0.25, 0.0625, 0.0)
+        f.depositVio(12.75, 0.25, -0.5, 0.125, 0.0)     # an uncommitted VIO delta (particleFilter.c:280-288)
+    a, b = g.getTagLoc(), o.getTagLoc()
+    assert a[0] == 1 and b[0] == 1 and a[1] == b[1] == 12.75
+    assert np.abs(np.array(a[2:], dtype=np.float64) - np.array(b[2:], dtype=np.float64)).max() <= 2e-6
+    # against float64 numpy as an independent check
+    w = p[:, 0].astype(np.float64)
+    th = np.arctan2((w * np.sin(p[:, 4].astype(np.float64))).sum(), (w * np.cos(p[:, 4].astype(np.float64))).sum())
+    assert abs(float(a[5]) - th) < 1e-5
+
+
+def test_uninitialised_filter_reports_zero(pfm):
+    g = pfm.DeviceParticleFilterLoc(1000, seed=1)
+    g.depositVio(1.0, 0.0, 0.0, 0.0, 0.0)
+    assert g.getTagLoc()[0] == 0
+    assert not g.initialized
+    g.depositRange(0.0, 0.0, 0.0, 2.0, 0.1)
+    assert g.initialized and g.getTagLoc()[0] == 1
+
+
+# ------------------------------------------------------------------ whole deposits
+def _drive(f, events):
+    poses = []
+    for ev in events:
+        if ev[0] == "vio":
+            f.depositVio(*ev[1:])
+        elif ev[0] == "range":
+            f.depositRange(*ev[1:])
+        else:
+            f.depositRssi(*ev[1:])
+        if ev[0] != "vio":
+            poses.append(f.getTagLoc())
+    return poses
+
+
+def _scene_events(n_steps):
+    bx, truth, rng = _synth.synthetic_scene(n_steps)
+    ev = []
+    for k in range(n_steps):
+        ev.append(("vio", 10.0 + 0.1 * k, float(truth[k, 0]), float(truth[k, 1]), float(truth[k, 2]), 0.0))
+        b = k % 8
+        ev.append(("range", float(bx[b, 0]), float(bx[b, 1]), float(bx[b, 2]), float(rng[k, 0]), 0.1))
+        if k % 3 == 2:
+            b2 = (k + 1) % 8
+            ev.append(("rssi", float(bx[b2, 0]), float(bx[b2, 1]), float(bx[b2, 2]), -55))
+    return ev
+
+
+@pytest.mark.parametrize("n", [10000, 50021])
+def test_deposit_sequence_tracks_oracle(pfm, ora, n):
+    """Config-3 style scene (8 beacons, circle walk): every deposit on the GPU vs the oracle with the same
+    Philox key.  Same branch decisions; per-particle state within float tolerance while no gate decision
+    flips (a particle within ~1e-6 m of the 3-sigma shell can gate differently: its weight then differs
+    by the factor minWeight, which the test allows for a handful of particles); poses within 1e-4."""
+    g, o = _pair(pfm, ora, n)
+    ev = _scene_events(24)
+    k = 0
+    for e in ev:
+        for f in (g, o):
+            _drive(f, [e])
+        if e[0] == "vio":
+            continue
+        k += 1
+        gs = g.last_stats() if k > 1 else None
+        if gs is not None:
+            os_ = o.last_stats()
+            assert int(gs["branch"]) == int(os_["branch"]), f"deposit {k}"
+            assert int(gs["numSpawn"]) == int(os_["numSpawn"])
+        a, b = g.getTagLoc(), o.getTagLoc()
+        assert np.abs(np.array(a[2:], dtype=np.float64) - np.array(b[2:], dtype=np.float64)).max() <= 1e-4, f"deposit {k}"
+    got, exp = g.download(), o.arrays()
+    wdiff = np.abs(got[0] - exp[0]) > 1e-5 * np.maximum(1.0, np.abs(exp[0]))
+    assert wdiff.sum() <= max(3, n // 5000)
+    for c in range(1, 4):
+        d = np.abs(got[c] - exp[c])
+        assert np.quantile(d, 0.999) <= 1e-4
+
+
+def test_rssi_is_fixed_range(pfm):
+    """depositRssi(b, any) == depositRange(b, 1.5, 0.5) (particleFilter.c:213-226): bitwise."""
+    a = pfm.DeviceParticleFilterLoc(20000, seed=9)
+    b = pfm.DeviceParticleFilterLoc(20000, seed=9)
+    for f, use_rssi in ((a, True), (b, False)):
+        f.depositVio(1.0, 0.0, 0.0, 0.0, 0.0)
+        f.depositRange(1.0, 1.0, 0.0, 2.0, 0.1)
+        f.depositVio(1.1, 0.05, 0.0, 0.0, 0.0)
+        for _ in range(3):
+            if use_rssi:
+                f.depositRssi(0.5, 0.5, 0.0, -70)
+            else:
+                f.depositRange(0.5, 0.5, 0.0, 1.5, 0.5)
+    for u, v in zip(a.download(), b.download()):
+        assert np.array_equal(u, v)
+
+
+def test_reference_layout_api_matches_extension(pfm, test1):
+    """The drop-in entry points (particleFilterLoc_* on a caller-owned 400 056-byte struct) run the same
+    kernels as the pfx_* filter: identical seed/stream -> identical poses, and pTag[] after
+    pfx_loc_sync_host equals the downloaded SoA state."""
+    from slam3d_amd import replay as R
+    vio, uwb, dep = test1
+    pfm.setSeed(SEED)
+    legacy = pfm.ParticleFilterLoc()
+    dev = legacy.device_filter()
+    ext = pfm.DeviceParticleFilterLoc(10000, seed=dev.seed, stream_id=dev.stream_id)
+    ra = R.replay_loc(legacy, vio, uwb, dep, max_events=400)
+    rb = R.replay_loc(ext, vio, uwb, dep, max_events=400)
+    assert len(ra.rows) == len(rb.rows) > 100
+    assert ra.csv_text() == rb.csv_text()
+    p = legacy.particles()
+    soa = ext.download()
+    for k in range(5):
+        assert np.array_equal(p[:, k], soa[k])
+
+
+def test_test1_replay_statistically_equivalent(pfm, test1):
+    """BASELINE config 1 trace on the GPU (Philox noise, so no sample-path parity with the rand_r goldens):
+    the estimate must stay within the seed-to-seed spread of the reference filter itself.  The spread was
+    measured with the oracle in reference arithmetic over rand_r seeds (tests/tools/seed_spread.py), against
+    the linux-gcc golden over rows 100..874: position RMS 0.10-0.20 m, worst row 1.1-2.9 m (the posterior is
+    multi-modal for a while), heading RMS 0.18-0.28 rad, final position within 0.025 m.  Thresholds are
+    1.5x the worst of those (4x for the final position)."""
+    from slam3d_amd import replay as R
+    vio, uwb, dep = test1
+    exp = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "test1",
+                                  "test1_ParticleFilterLoc_expected_out_linux-gcc.csv"), delimiter=",", skiprows=1)
+    exp = exp[:, [0, 3, 1, 2, 4]]                    # file order t,y,z,x,theta -> t,x,y,z,theta
+    g = pfm.DeviceParticleFilterLoc(10000, seed=SEED)
+    res = R.replay_loc(g, vio, uwb, dep)
+    got = res.as_array()
+    assert got.shape == exp.shape == (875, 5)
+    assert np.abs(got[:, 0] - exp[:, 0]).max() < 1e-6          # the golden prints t with 6 decimals
+    d = np.linalg.norm(got[100:, 1:4] - exp[100:, 1:4], axis=1)
+    assert np.sqrt((d ** 2).mean()) < 0.30 and d.max() < 4.4
+    dth = np.angle(np.exp(1j * (got[100:, 4] - exp[100:, 4])))
+    assert np.sqrt((dth ** 2).mean()) < 0.42
+    assert np.linalg.norm(got[-1, 1:4] - exp[-1, 1:4]) < 0.10
