@@ -180,6 +180,22 @@ __device__ __forceinline__ double block_inclusive_scan(double v, double* lds, do
     return v + pre;
 }
 
+// Inclusive running maximum of one double per thread across a 256-thread block (exact: max is
+// associative).  Used to make a parallel prefix sum non-decreasing.  `lds` holds 4 doubles.
+__device__ __forceinline__ double block_inclusive_max(double v, double* lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double up = __shfl_up(v, off, 64);
+        if (lane >= off) v = up > v ? up : v;
+    }
+    if (lane == 63) lds[wave] = v;
+    __syncthreads();
+    for (int k = 0; k < wave; ++k) v = lds[k] > v ? lds[k] : v;
+    return v;
+}
+
 // first j in [0, n) with u < cdf[j]; n-1 if there is none (pfResample.c:70-72 with the clamp)
 template <typename T>
 __device__ __forceinline__ int upper_bound_clamped(const T* cdf, int n, T u)

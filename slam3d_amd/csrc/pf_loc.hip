@@ -86,8 +86,10 @@ struct pfx_loc {
     LocBufs bufs{};
     double* tileSums = nullptr;     // numTiles * kSumsPerTile
     double* rsPart = nullptr;       // numTiles * kRsPerTile
-    double* tileBase = nullptr;     // numTiles + 1
-    long long* firstOut = nullptr;  // numTiles + 1
+    double* tileIncl = nullptr;     // numTiles: prefix of the tile weights inside their chunk
+    double* chunkSums = nullptr;    // numChunks * kSumsPerTile
+    double* chunkBase = nullptr;    // numChunks + 1
+    int numChunks = 0;
     unsigned char* branchLog = nullptr; // kBranchLogSize
     int* anc = nullptr;             // n, only while recording
     bool recordAnc = false;
@@ -162,8 +164,11 @@ int launch_stream(pfx_loc* pf, bool motion, bool gate, const Motion& mo, const G
 int launch_decide(pfx_loc* pf, float range)
 {
     ProfScope ps(pf, PFX_K_DECIDE);
-    hipLaunchKernelGGL(k_loc_decide, dim3(1), dim3(kDecideThreads), 0, pf->stream, pf->ctl, pf->tileSums, pf->tileBase,
-                       pf->firstOut, pf->numTiles, pf->n, range, key_of(pf), pf->force, pf->branchLog);
+    hipLaunchKernelGGL(k_loc_chunks, dim3(pf->numChunks), dim3(kChunkTiles), 0, pf->stream, pf->tileSums, pf->tileIncl,
+                       pf->chunkSums, pf->numTiles);
+    if (check_launch("k_loc_chunks")) return -1;
+    hipLaunchKernelGGL(k_loc_decide, dim3(1), dim3(kDecideThreads), 0, pf->stream, pf->ctl, pf->chunkSums, pf->chunkBase,
+                       pf->numChunks, pf->n, range, key_of(pf), pf->force, pf->branchLog);
     return check_launch("k_loc_decide");
 }
 
@@ -172,11 +177,11 @@ int launch_resample(pfx_loc* pf, float bx, float by, float bz, float range, floa
     ProfScope ps(pf, PFX_K_RESAMPLE);
     const dim3 grid(pf->numTiles), block(kThreads);
     if (pf->recordAnc)
-        hipLaunchKernelGGL((k_loc_resample<true>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->tileBase, pf->firstOut,
-                           pf->rsPart, pf->anc, pf->n, key_of(pf), bx, by, bz, range, stdRange);
+        hipLaunchKernelGGL((k_loc_resample<true>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->chunkBase, pf->tileIncl,
+                           pf->rsPart, pf->anc, pf->numTiles, pf->n, key_of(pf), bx, by, bz, range, stdRange);
     else
-        hipLaunchKernelGGL((k_loc_resample<false>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->tileBase, pf->firstOut,
-                           pf->rsPart, (int*)nullptr, pf->n, key_of(pf), bx, by, bz, range, stdRange);
+        hipLaunchKernelGGL((k_loc_resample<false>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->chunkBase, pf->tileIncl,
+                           pf->rsPart, (int*)nullptr, pf->numTiles, pf->n, key_of(pf), bx, by, bz, range, stdRange);
     return check_launch("k_loc_resample");
 }
 
@@ -214,8 +219,9 @@ void free_device(pfx_loc* pf)
     if (pf->slab) hipFree(pf->slab);
     if (pf->tileSums) hipFree(pf->tileSums);
     if (pf->rsPart) hipFree(pf->rsPart);
-    if (pf->tileBase) hipFree(pf->tileBase);
-    if (pf->firstOut) hipFree(pf->firstOut);
+    if (pf->tileIncl) hipFree(pf->tileIncl);
+    if (pf->chunkSums) hipFree(pf->chunkSums);
+    if (pf->chunkBase) hipFree(pf->chunkBase);
     if (pf->anc) hipFree(pf->anc);
     if (pf->branchLog) hipFree(pf->branchLog);
     if (pf->ctl) hipFree(pf->ctl);
@@ -237,8 +243,10 @@ int alloc_device(pfx_loc* pf)
     const size_t nt = (size_t)pf->numTiles;
     PF_HIP_OK(hipMalloc((void**)&pf->tileSums, nt * kSumsPerTile * sizeof(double)));
     PF_HIP_OK(hipMalloc((void**)&pf->rsPart, nt * kRsPerTile * sizeof(double)));
-    PF_HIP_OK(hipMalloc((void**)&pf->tileBase, (nt + 1) * sizeof(double)));
-    PF_HIP_OK(hipMalloc((void**)&pf->firstOut, (nt + 1) * sizeof(long long)));
+    const size_t nc = (size_t)pf->numChunks;
+    PF_HIP_OK(hipMalloc((void**)&pf->tileIncl, nt * sizeof(double)));
+    PF_HIP_OK(hipMalloc((void**)&pf->chunkSums, nc * kSumsPerTile * sizeof(double)));
+    PF_HIP_OK(hipMalloc((void**)&pf->chunkBase, (nc + 1) * sizeof(double)));
     PF_HIP_OK(hipMemsetAsync(pf->tileSums, 0, nt * kSumsPerTile * sizeof(double), pf->stream));
     PF_HIP_OK(hipMemsetAsync(pf->rsPart, 0, nt * kRsPerTile * sizeof(double), pf->stream));
     PF_HIP_OK(hipMalloc((void**)&pf->branchLog, kBranchLogSize));
@@ -268,7 +276,7 @@ extern "C" int pfx_device_count(void)
 extern "C" pfx_loc* pfx_loc_create(int64_t n, uint32_t seed, uint32_t stream_id, int device)
 {
     clear_error();
-    if (n < 1 || n > (int64_t)1 << 31) { set_error("pfx_loc_create: n=%lld out of range [1, 2^31]", (long long)n); return nullptr; }
+    if (n < 1 || n > (int64_t)1 << 28) { set_error("pfx_loc_create: n=%lld out of range [1, 2^28]", (long long)n); return nullptr; }
     const int ndev = pfx_device_count();
     if (ndev <= 0) { set_error("pfx_loc_create: no HIP device visible"); return nullptr; }
     if (device < 0 || device >= ndev) { set_error("pfx_loc_create: device %d not in [0,%d)", device, ndev); return nullptr; }
@@ -278,6 +286,7 @@ extern "C" pfx_loc* pfx_loc_create(int64_t n, uint32_t seed, uint32_t stream_id,
     pf->n = n;
     pf->numTiles = (int)((n + kTile - 1) / kTile);
     pf->padded = (size_t)pf->numTiles * kTile;
+    pf->numChunks = (pf->numTiles + kChunkTiles - 1) / kChunkTiles;
     pf->seed = seed;
     pf->streamId = stream_id;
     DeviceGuard g(device);

@@ -1,17 +1,26 @@
 // pf_loc_kernels.h -- HIP kernels of the particleFilterLoc hot path (gfx950, wave64).
 //
-// One deposit (particleFilter.c:178-191) is three launches on the filter's stream, no host sync:
+// One deposit (particleFilter.c:178-191) is four launches on the filter's stream, no host sync:
 //   k_loc_stream   VIO motion (pfMeasurement.c:24-49) + range gate (:108-125) + weight/pose sums
 //                  (pfResample.c:41-50, particleFilter.c:263-273) in ONE pass over the SoA arrays;
 //                  per-tile partial sums by wave shuffles + LDS.                       [HBM-bound]
-//   k_loc_decide   one workgroup: tile prefix (f64), ESS / respawn test, bandwidth, rStart (Philox),
-//                  first-offspring index of every tile (pfResample.c:51-68).           [tiny]
+//   k_loc_chunks   one workgroup per 256 tiles: sums of the tile sums and the in-chunk prefix of the
+//                  tile weights.                                                       [tiny]
+//   k_loc_decide   one workgroup: prefix over chunks (f64), ESS / respawn test, heading bandwidth,
+//                  rStart from Philox (pfResample.c:51-68).                            [tiny]
 //   k_loc_resample systematic resampling (pfResample.c:70-76): each workgroup rebuilds its tile's
 //                  CDF in LDS, binary-searches the ancestors of its contiguous offspring range,
 //                  gathers, jitters (pfInit.c:68-79), respawns (pfInit.c:56-66) and writes the
 //                  other ping-pong buffer; exits at once on a normalise-only step.      [HBM-bound]
 // The normalisation of a non-resampling step (pfResample.c:80-82, w *= N/s) is not a pass: the factor
 // is kept in the control block and multiplied in by the next reader of w (same product, same rounding).
+//
+// CDF rule.  The reference keeps a serial float32 running sum (pfResample.c:45,49), which is void for
+// N >= 2^24.  Here the CDF value of particle j of tile t is  B(t) + (inclusive f64 scan inside the tile),
+// with B(t) = chunkBase[t / 256] + (f64 prefix of the tile sums inside the chunk); every sum is float64 over
+// the float32 weights.  Offspring i sits at u_i = rStart + rStep * i (f64, rStep = S / N) and descends
+// from the first particle whose CDF value exceeds u_i; offspring that fall off the end go to the last
+// particle (the reference reads out of bounds there).
 #pragma once
 
 #include "pf_common.h"
@@ -41,6 +50,8 @@ struct Gate { float bx, by, bz, range, thresh, minWeight; };
 
 constexpr int kSumsPerTile = 8;     // s ss c sn wx wy wz (pad)
 constexpr int kRsPerTile = 8;       // x y z c sn count (pad)
+constexpr int kChunkTiles = 256;    // tiles per chunk of the two-level prefix
+constexpr int kMaxChunks = 8192;    // 8192 * 256 * 1024 = 2^31 particles
 
 // ------------------------------------------------------------------ streaming pass
 template <bool MOTION, bool GATE>
@@ -131,6 +142,37 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
     }
 }
 
+// ------------------------------------------------------------------ two-level prefix, level 1
+// Workgroup c sums the seven per-tile sums of its 256 tiles (-> chunkSums[c]) and writes the inclusive
+// prefix of the tile weights inside the chunk (-> tileIncl[t]), made non-decreasing with a max-scan so that
+// rounding in the parallel scan can never order two tile boundaries the wrong way round.
+__global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(const double* __restrict__ tileSums, double* __restrict__ tileIncl,
+                                                           double* __restrict__ chunkSums, int numTiles)
+{
+    __shared__ double red[4 * 7];
+    __shared__ double sc[4];
+    const int t = blockIdx.x * kChunkTiles + threadIdx.x;
+    double v[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    if (t < numTiles) {
+        const double* p = tileSums + (size_t)t * kSumsPerTile;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = p[k];
+    }
+    double total;
+    double incl = block_inclusive_scan(v[0], sc, total);
+    __syncthreads();
+    incl = block_inclusive_max(incl, sc);
+    if (t < numTiles) tileIncl[t] = incl;
+    __syncthreads();
+    block_sum<7>(v, red);
+    if (threadIdx.x == kChunkTiles - 1) chunkSums[(size_t)blockIdx.x * kSumsPerTile] = incl;     // == last prefix, not a re-sum
+    if (threadIdx.x == 0) {
+        double* o = chunkSums + (size_t)blockIdx.x * kSumsPerTile;
+#pragma unroll
+        for (int k = 1; k < 7; ++k) o[k] = v[k];
+    }
+}
+
 // ------------------------------------------------------------------ decision (one workgroup)
 constexpr int kDecideThreads = 1024;
 
@@ -147,26 +189,23 @@ __device__ __forceinline__ double block1024_sum(double v, double* lds16)
 }
 
 // force: -1 follow the reference's test, 0 never resample, 1 always resample (worst-case traffic runs)
-__global__ __launch_bounds__(kDecideThreads) void k_loc_decide(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
-                                                              double* __restrict__ tileBase, long long* __restrict__ firstOut,
-                                                              int numTiles, long long n, float range, RngKey key, int force,
+__global__ __launch_bounds__(kDecideThreads) void k_loc_decide(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
+                                                              double* __restrict__ chunkBase, int numChunks, long long n,
+                                                              float range, RngKey key, int force,
                                                               unsigned char* __restrict__ branchLog)
 {
     __shared__ double lds16[16];
-    __shared__ double shS, shStart, shStep;
-    __shared__ int shBranch;
+    __shared__ double shS;
 
+    // one chunk per thread (numChunks <= 1024, i.e. n <= 2^28 particles per filter)
     const int tid = threadIdx.x;
-    const int chunk = (numTiles + kDecideThreads - 1) / kDecideThreads;
-    const int begin = min(tid * chunk, numTiles), end = min(begin + chunk, numTiles);
-
     double loc[7] = { 0, 0, 0, 0, 0, 0, 0 };
-    for (int t = begin; t < end; ++t) {
-        const double* p = tileSums + (size_t)t * kSumsPerTile;
+    if (tid < numChunks) {
+        const double* p = chunkSums + (size_t)tid * kSumsPerTile;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) loc[k] += p[k];
+        for (int k = 0; k < 7; ++k) loc[k] = p[k];
     }
-    // exclusive scan of the per-thread weight totals (wave scan + 16 wave totals)
+    // exclusive prefix of the chunk weights: wave scan + the 16 wave totals
     double inc = loc[0];
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -178,12 +217,24 @@ __global__ __launch_bounds__(kDecideThreads) void k_loc_decide(LocCtl* __restric
     __syncthreads();
     double pre = 0.0;
     for (int k = 0; k < wave; ++k) pre += lds16[k];
-    double run = pre + (inc - loc[0]);
-    for (int t = begin; t < end; ++t) {
-        tileBase[t] = run;
-        run += tileSums[(size_t)t * kSumsPerTile];
+    const double exclInWave = __shfl_up(inc, 1, 64);
+    double start = pre + (lane == 0 ? 0.0 : exclInWave);
+    // make the chunk bases non-decreasing whatever the rounding of the parallel scan did (max-scan)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double up = __shfl_up(start, off, 64);
+        if (lane >= off) start = up > start ? up : start;
     }
-    if (end == numTiles && begin < end) { tileBase[numTiles] = run; shS = run; }
+    __syncthreads();
+    if (lane == 63) lds16[wave] = start;
+    __syncthreads();
+    for (int k = 0; k < wave; ++k) start = lds16[k] > start ? lds16[k] : start;
+    if (tid < numChunks) chunkBase[tid] = start;
+    if (tid == numChunks - 1) {
+        const double S = start + loc[0];
+        chunkBase[numChunks] = S;
+        shS = S;
+    }
 
     double tot[7];
     tot[0] = 0.0;
@@ -218,7 +269,6 @@ __global__ __launch_bounds__(kDecideThreads) void k_loc_decide(LocCtl* __restric
             ctl->htheta = h; ctl->rStep = rStep; ctl->rStart = rStart;
             ctl->src = cur; ctl->dst = cur ^ 1; ctl->cur = cur ^ 1;
             ctl->wscale = 1.0f; ctl->m = 0.0f; ctl->branch = 1;
-            shStart = rStart; shStep = rStep;
         } else {
             // pfResample.c:80-82, deferred: the next reader multiplies w by m
             const float m = (float)n / s;
@@ -226,38 +276,44 @@ __global__ __launch_bounds__(kDecideThreads) void k_loc_decide(LocCtl* __restric
             ctl->pose[0] = S; ctl->pose[1] = tot[4]; ctl->pose[2] = tot[5]; ctl->pose[3] = tot[6];
             ctl->pose[4] = tot[2]; ctl->pose[5] = tot[3];
         }
-        shBranch = resample ? 1 : 0;
         const long long k = ctl->nDecisions;
         branchLog[k % kBranchLogSize] = resample ? 1 : 0;
         ctl->nDecisions = k + 1;
     }
-    __syncthreads();
-    if (!shBranch) return;
+}
 
-    // first offspring of every tile: the number of i in [0,n) with rStart + rStep*i < tileBase[t]
-    const double rStart = shStart, rStep = shStep;
-    const bool sane = (rStep > 0.0) && (rStep < 1e300);
-    for (int t = begin; t < end; ++t) {
-        long long f = 0;
-        if (t > 0 && sane) {
-            const double b = tileBase[t];
-            const double q = ceil((b - rStart) / rStep);
-            f = q < 0.0 ? 0 : (q > (double)n ? n : (long long)q);
-            for (int it = 0; it < 8 && f > 0 && !(rStart + rStep * (double)(f - 1) < b); ++it) --f;
-            for (int it = 0; it < 8 && f < n && (rStart + rStep * (double)f < b); ++it) ++f;
-        }
-        firstOut[t] = f;
-    }
-    if (tid == 0) firstOut[numTiles] = n;
+// CDF value at the START of tile t (t in [0, numTiles]).  The same expression is evaluated by the
+// workgroups on both sides of a boundary, and it is non-decreasing in t: inside a chunk tileIncl is
+// non-decreasing and the sum is capped by the next chunk's base.
+__device__ __forceinline__ double tile_start_cdf(const double* __restrict__ chunkBase, const double* __restrict__ tileIncl, int t)
+{
+    const int c = t / kChunkTiles;
+    if (t % kChunkTiles == 0) return chunkBase[c];
+    const double v = chunkBase[c] + tileIncl[t - 1];
+    const double cap = chunkBase[c + 1];
+    return v < cap ? v : cap;
+}
+
+// Number of offspring i in [0,n) with rStart + rStep*i < b (u_i is non-decreasing in i), i.e. the first
+// offspring that does not precede CDF value b.
+__device__ __forceinline__ long long first_offspring_at(double b, double rStart, double rStep, long long n)
+{
+    if (!((rStep > 0.0) && (rStep < 1e300))) return 0;      // zero / non-finite total weight: all to the last tile
+    const double q = ceil((b - rStart) / rStep);
+    if (!(q == q)) return 0;
+    long long f = q < 0.0 ? 0 : (q > (double)n ? n : (long long)q);
+    for (int it = 0; it < 8 && f > 0 && !(rStart + rStep * (double)(f - 1) < b); ++it) --f;
+    for (int it = 0; it < 8 && f < n && (rStart + rStep * (double)f < b); ++it) ++f;
+    return f;
 }
 
 // ------------------------------------------------------------------ resample
 template <bool RECORD>
 __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const LocCtl* __restrict__ ctl,
-                                                          const double* __restrict__ tileBase,
-                                                          const long long* __restrict__ firstOut,
+                                                          const double* __restrict__ chunkBase,
+                                                          const double* __restrict__ tileIncl,
                                                           double* __restrict__ rsPart, int* __restrict__ ancOut,
-                                                          long long n, RngKey key, float bx, float by, float bz,
+                                                          int numTiles, long long n, RngKey key, float bx, float by, float bz,
                                                           float range, float stdRange)
 {
     if (ctl->branch != 1) return;           // normalise-only step: nothing to do (wave-uniform exit)
@@ -265,7 +321,11 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
     __shared__ double cdf[kTile];
     __shared__ double red[4 * 6];
     const int t = blockIdx.x, tid = threadIdx.x;
-    const long long i0 = firstOut[t], i1 = firstOut[t + 1];
+    const double rStart = ctl->rStart, rStep = ctl->rStep;
+    const double tileStart = tile_start_cdf(chunkBase, tileIncl, t);
+    const long long i0 = (t == 0) ? 0 : first_offspring_at(tileStart, rStart, rStep, n);
+    const long long i1 = (t == numTiles - 1) ? n
+                                             : first_offspring_at(tile_start_cdf(chunkBase, tileIncl, t + 1), rStart, rStep, n);
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
 
     if (i0 < i1) {
@@ -281,13 +341,13 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
         float* __restrict__ dz = bufs.a[dst][3];
         float* __restrict__ dt = bufs.a[dst][4];
 
-        // this tile's CDF, rebuilt from the weights (pfResample.c:45,49 in double): base + inclusive scan
+        // this tile's CDF, rebuilt from the weights (pfResample.c:45,49 in double): tile start + inclusive scan
         const long long tbase = (long long)t * kTile;
         const float4 w4 = *reinterpret_cast<const float4*>(sw + tbase + tid * kPerThread);
         const double a0 = w4.x, a1 = a0 + w4.y, a2 = a1 + w4.z, a3 = a2 + w4.w;
         double total;
         const double incl = block_inclusive_scan(a3, red, total);
-        const double off = tileBase[t] + (incl - a3);
+        const double off = tileStart + (incl - a3);
         cdf[tid * 4 + 0] = off + a0;
         cdf[tid * 4 + 1] = off + a1;
         cdf[tid * 4 + 2] = off + a2;
@@ -296,7 +356,6 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
 
         const long long rem = n - tbase;
         const int nValid = rem < kTile ? (int)rem : kTile;
-        const double rStart = ctl->rStart, rStep = ctl->rStep;
         const float hTheta = ctl->htheta;
         const int numSpawn = ctl->numSpawn;
 
@@ -399,7 +458,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_pose(LocCtl* __restrict__ ctl,
 // ------------------------------------------------------------------ index selection on a caller CDF
 // anc[i] = first j with rStart + rStep*i < cdf[j], else n-1 (pfResample.c:70-72).  T = float reproduces the
 // reference's float expression exactly (no fused multiply-add: -ffp-contract=off); T = double is the
-// production rule.  Same upper_bound_clamped as k_loc_resample, on global memory.
+// production rule.  Same search as upper_bound_clamped in k_loc_resample, on global memory.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_resample_indices(const T* __restrict__ cdf, long long n, T rStart, T rStep,
                                                               int* __restrict__ anc)
