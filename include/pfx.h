@@ -99,6 +99,31 @@ int64_t  pfx_loc_profile_records(pfx_loc* pf, int32_t* kind, float* ms, int64_t 
  * last 65536; *total = number of decisions so far.  Synchronises the stream. */
 int64_t  pfx_loc_branch_log(pfx_loc* pf, uint8_t* out, int64_t cap, int64_t* total);
 
+/* ---- one filter sharded by particle range over several GPUs (no counterpart in the reference) ----
+ * The caller owns the collectives (slam3d_amd/sharded.py uses torch.distributed = RCCL); these are the local
+ * halves of a deposit.  The shard created with pfx_loc_create(n_local, ...) holds the global particles
+ * [self_begin, self_begin + n_local) of a filter of n_global; noise is keyed by global index.  Per deposit:
+ *   pfx_loc_shard_pass1    VIO commit + streaming pass + local tile prefix; 8 local sums land in device memory
+ *                          (returns 1 instead if the filter was uninitialised and has just spawned its particles)
+ *   all-gather             of pfx_loc_shard_local_ptr (8 doubles) into pfx_loc_shard_all_ptr (rank-major), by the caller
+ *   pfx_loc_shard_decide   the reference's ESS / respawn decision on the GLOBAL totals, identical on every rank;
+ *                          F[g] = first global offspring index produced by shard g (F[num_shards] = n_global)
+ *   pfx_loc_shard_resample offspring of the local ancestors: those with index inside the shard's own range go to
+ *                          the new current arrays, the rest to the staging arrays (first those below the range,
+ *                          then those above); the caller ships them into the owners' current arrays and sets
+ *                          their weights with pfx_loc_shard_fill_w.  Fails if the staging area is too small. */
+int      pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64_t n_global, int64_t self_begin, int64_t stage_capacity);
+int      pfx_loc_shard_pass1(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);
+void*    pfx_loc_shard_local_ptr(pfx_loc* pf);      /* device address: s ss csum ssum wx wy wz 0 */
+void*    pfx_loc_shard_all_ptr(pfx_loc* pf);        /* device address: 16 x 8 doubles */
+int      pfx_loc_shard_decide(pfx_loc* pf, float range, int* out_branch, int64_t* out_F);
+int      pfx_loc_shard_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);
+int      pfx_loc_shard_ptrs(pfx_loc* pf, void* d_stage[4], void* d_current[5]);
+int      pfx_loc_shard_fill_w(pfx_loc* pf, int cur, int64_t begin, int64_t count);
+int      pfx_loc_shard_pose_sums(pfx_loc* pf, double out[6]);   /* local sums of w, wx, wy, wz, w cos, w sin */
+/* particleFilter.c:274-290 on caller-supplied (e.g. all-reduced) pose sums; 1 ok, 0 not initialised */
+int      pfx_loc_pose_from_sums(pfx_loc* pf, const double sums[6], double* t, float* x, float* y, float* z, float* theta);
+
 /* ---- binding between the reference-layout structs and device filters ---- */
 pfx_loc* pfx_loc_of(const particleFilterLoc_t* pf);          /* NULL if the struct is not bound */
 int      pfx_loc_sync_host(particleFilterLoc_t* pf);         /* fill pf->pTag[] (AoS) from HBM */

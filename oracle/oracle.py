@@ -77,6 +77,10 @@ def lib() -> C.CDLL:
     sig("ora_loc_last_stats", None, vp, pd_)
     sig("ora_loc_last_ancestors", pi_, vp)
     sig("ora_loc_last_cdf", pd_, vp)
+    sig("ora_loc_set_index_offset", None, vp, u64)
+    sig("ora_offspring_block", None, vp, u32, u32, C.c_int64, i, pi_, pf_, pf_, pf_, pf_, f, i, f, f, f, f, f,
+        pf_, pf_, pf_, pf_)
+    sig("ora_decide", None, vp, u32, u32, d, d, d, d, C.c_int64, f, i, pd_)
     sig("ora_clamp_events", C.c_long)
     sig("ora_resample_indices_f32", None, pf_, i, f, f, pi_)
     sig("ora_resample_indices_f64", None, pd_, i, d, d, pi_)

@@ -239,6 +239,16 @@ static void motion_one(soa_t* p, size_t i, ora_rng* rng, float dx, float dy, flo
     p->th[i] = fmodf(th + stdTheta * rth, TWO_PI_F);
 }
 
+static void motion_all_from(soa_t* p, size_t n, ora_rng* rng, uint32_t stream, uint32_t epoch, const float d[5], uint64_t idx0)
+{
+    float stdXyz = sqrtf(d[4]) * VIO_STD_XYZ;
+    float stdTheta = sqrtf(d[0]) * VIO_STD_THETA;
+    for (size_t i = 0; i < n; ++i) {
+        ora_rng_begin(rng, stream, epoch, ORA_P_VIO, idx0 + i);
+        motion_one(p, i, rng, d[1], d[2], d[3], stdXyz, stdTheta);
+    }
+}
+
 static void motion_all(soa_t* p, size_t n, ora_rng* rng, uint32_t stream, uint32_t epoch, const float d[5])
 {
     float stdXyz = sqrtf(d[4]) * VIO_STD_XYZ;
@@ -452,6 +462,7 @@ struct ora_loc {
     vio_t v;
     ora_rng* rng;
     uint32_t epoch;
+    uint64_t idx0;          /* global index of particle 0 when this filter is one shard of a larger one */
     rs_stats_t st;
 };
 
@@ -488,7 +499,7 @@ void ora_loc_deposit_vio(ora_loc* pf, double t, float x, float y, float z, float
 void ora_loc_apply_vio(ora_loc* pf, float dt, float dx, float dy, float dz, float ddist)
 {
     float d[5] = { dt, dx, dy, dz, ddist };
-    motion_all(&pf->p, (size_t)pf->n, pf->rng, 0, pf->epoch, d);
+    motion_all_from(&pf->p, (size_t)pf->n, pf->rng, 0, pf->epoch, d, pf->idx0);
 }
 
 /* pfMeasurement.c:108-125 -- hard 3-sigma range gate */
@@ -514,8 +525,74 @@ void ora_loc_resample(ora_loc* pf, float bx, float by, float bz, float range, fl
 void ora_loc_spawn_all(ora_loc* pf, float bx, float by, float bz, float range, float stdRange)
 {
     for (int i = 0; i < pf->n; ++i) {
-        ora_rng_begin(pf->rng, 0, pf->epoch, ORA_P_SPAWN, (uint64_t)i);
+        ora_rng_begin(pf->rng, 0, pf->epoch, ORA_P_SPAWN, pf->idx0 + (uint64_t)i);
         spawn_from_range(&pf->p, (size_t)i, pf->rng, bx, by, bz, range, stdRange);
+    }
+}
+
+/* particleFilter.c:389-404 on its own, and particleFilter.c:274-290 on caller-supplied sums (sharded test double) */
+void ora_loc_commit_vio(ora_loc* pf, float d[5]) { vio_commit(&pf->v, d); }
+int ora_loc_pose_from_sums(const ora_loc* pf, const double p[6], double* t, float* x, float* y, float* z, float* theta)
+{
+    if (!pf->v.initialized) return 0;
+    float s = (float)p[0], xs = (float)p[1], ys = (float)p[2], zs = (float)p[3], cs = (float)p[4], sn = (float)p[5];
+    const vio_t* v = &pf->v;
+    *t = v->lastT;
+    *x = xs / s; *y = ys / s; *z = zs / s;
+    *theta = atan2f(sn, cs);
+    float dx = v->lastX - v->firstX, dy = v->lastY - v->firstY, dz = v->lastZ - v->firstZ;
+    float co = cosf(*theta), si = sinf(*theta);
+    *x += dx * co - dy * si;
+    *y += dx * si + dy * co;
+    *z += dz;
+    return 1;
+}
+
+/* ---- helpers for the sharded-filter test double (tests/_oracle_shard.py); Philox mode only ---- */
+void ora_loc_set_index_offset(ora_loc* pf, uint64_t idx0) { pf->idx0 = idx0; }
+
+/* Offspring i_begin .. i_begin+count-1 of a resampling step, given their ancestors (indices into the src
+ * arrays): the first numSpawn global indices are respawned on the range shell (pfResample.c:75-76), the
+ * others are jittered copies (pfInit.c:68-79).  Noise keyed by the GLOBAL offspring index. */
+void ora_offspring_block(ora_rng* rng, uint32_t stream, uint32_t epoch, int64_t i_begin, int count, const int* anc,
+                         const float* sx, const float* sy, const float* sz, const float* sth, float hTheta, int numSpawn,
+                         float cx, float cy, float cz, float range, float stdRange,
+                         float* ox, float* oy, float* oz, float* oth)
+{
+    float one;
+    soa_t src = { (float*)sx, (float*)sx, (float*)sy, (float*)sz, (float*)sth };
+    for (int k = 0; k < count; ++k) {
+        int64_t i = i_begin + k;
+        soa_t dst = { &one, ox + k, oy + k, oz + k, oth + k };
+        if (i < numSpawn) {
+            ora_rng_begin(rng, stream, epoch, ORA_P_SPAWN, (uint64_t)i);
+            spawn_from_range(&dst, 0, rng, cx, cy, cz, range, stdRange);
+        } else {
+            ora_rng_begin(rng, stream, epoch, ORA_P_JITTER, (uint64_t)i);
+            spawn_from_other(&dst, 0, &src, (size_t)anc[k], rng, HXYZ, hTheta);
+        }
+    }
+}
+
+/* the scalar decision of pfResample.c:51-68,80 on given f64 totals (f64 rule); out: branch numSpawn htheta m rStart rStep */
+void ora_decide(ora_rng* rng, uint32_t stream, uint32_t epoch, double S, double SS, double C, double SN, int64_t n,
+                float range, int force, double out[6])
+{
+    float s = (float)S, ss = (float)SS, csum = (float)C, ssum = (float)SN;
+    float ess = s * s / ss;
+    float invN = 1.0f / (float)n;
+    int numSpawn = 0;
+    if (s * invN < WEIGHT_SPAWN_THRESH && range < RADIUS_SPAWN_THRESH) numSpawn = (int)lroundf((float)n * PCT_SPAWN);
+    int resample = (ess * invN < RESAMPLE_THRESH) || numSpawn > 0;
+    if (force >= 0) resample = force != 0;
+    out[0] = resample; out[1] = numSpawn; out[2] = out[3] = out[4] = out[5] = 0.0;
+    if (resample) {
+        out[2] = theta_bandwidth(csum, ssum, s, ess);
+        ora_rng_begin(rng, stream, epoch, ORA_P_RSTART, 0);
+        out[5] = S / (double)n;
+        out[4] = (double)ora_rng_uniform(rng) * out[5];
+    } else {
+        out[3] = (float)n / s;
     }
 }
 

@@ -79,6 +79,17 @@ void       ora_loc_last_stats(const ora_loc* pf, double out[12]);
 const int* ora_loc_last_ancestors(const ora_loc* pf);
 const double* ora_loc_last_cdf(const ora_loc* pf);
 
+/* helpers for the sharded-filter test double (Philox mode) */
+void     ora_loc_set_index_offset(ora_loc* pf, uint64_t idx0);
+void     ora_loc_commit_vio(ora_loc* pf, float d[5]);
+int      ora_loc_pose_from_sums(const ora_loc* pf, const double p[6], double* t, float* x, float* y, float* z, float* theta);
+void     ora_offspring_block(ora_rng* rng, uint32_t stream, uint32_t epoch, int64_t i_begin, int count, const int* anc,
+                             const float* sx, const float* sy, const float* sz, const float* sth, float hTheta, int numSpawn,
+                             float cx, float cy, float cz, float range, float stdRange,
+                             float* ox, float* oy, float* oz, float* oth);
+void     ora_decide(ora_rng* rng, uint32_t stream, uint32_t epoch, double S, double SS, double C, double SN, int64_t n,
+                    float range, int force, double out[6]);
+
 /* systematic-resample index selection exactly as pfResample.c:70-72 walks it, on a caller CDF */
 long ora_clamp_events(void);   /* offspring clamped to the last ancestor so far (reference: out-of-bounds read) */
 void ora_resample_indices_f32(const float* cdf, int n, float rStart, float rStep, int* anc);

@@ -100,6 +100,14 @@ struct pfx_loc {
     bool poseDirty = true;
     int force = -1;
     VioState vio;
+    // sharding (pfx_loc_shard_*): this filter holds global particles [selfBegin, selfBegin + n)
+    int rank = 0, numShards = 1;
+    long long nGlobal = 0, selfBegin = 0;
+    size_t stageCap = 0;
+    float* stageSlab = nullptr;     // 4 arrays of stageCap floats
+    double* dAll = nullptr;         // kMaxShards * 8 gathered sums
+    ShardPlan* dPlan = nullptr;
+    ShardPlan* hostPlan = nullptr;  // pinned
     // profiling
     std::vector<ProfRec> prof;
     size_t profUsed = 0;
@@ -152,7 +160,7 @@ int launch_stream(pfx_loc* pf, bool motion, bool gate, const Motion& mo, const G
     const dim3 grid(pf->numTiles), block(kThreads);
     const RngKey key = key_of(pf);
 #define PF_LAUNCH_STREAM(M, G) \
-    hipLaunchKernelGGL((k_loc_stream<M, G>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->tileSums, pf->n, key, mo, ga)
+    hipLaunchKernelGGL((k_loc_stream<M, G>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->tileSums, pf->n, pf->selfBegin, key, mo, ga)
     if (motion && gate) PF_LAUNCH_STREAM(true, true);
     else if (motion) PF_LAUNCH_STREAM(true, false);
     else if (gate) PF_LAUNCH_STREAM(false, true);
@@ -161,14 +169,18 @@ int launch_stream(pfx_loc* pf, bool motion, bool gate, const Motion& mo, const G
     return check_launch("k_loc_stream");
 }
 
-int launch_decide(pfx_loc* pf, float range)
+int launch_decide(pfx_loc* pf, float range, bool localOnly = false)
 {
     ProfScope ps(pf, PFX_K_DECIDE);
     hipLaunchKernelGGL(k_loc_chunks, dim3(pf->numChunks), dim3(kChunkTiles), 0, pf->stream, pf->tileSums, pf->tileIncl,
                        pf->chunkSums, pf->numTiles);
     if (check_launch("k_loc_chunks")) return -1;
-    hipLaunchKernelGGL(k_loc_decide, dim3(1), dim3(kDecideThreads), 0, pf->stream, pf->ctl, pf->chunkSums, pf->chunkBase,
-                       pf->numChunks, pf->n, range, key_of(pf), pf->force, pf->branchLog);
+    if (localOnly)
+        hipLaunchKernelGGL((k_loc_decide<true>), dim3(1), dim3(kDecideThreads), 0, pf->stream, pf->ctl, pf->chunkSums,
+                           pf->chunkBase, pf->numChunks, pf->n, range, key_of(pf), pf->force, pf->branchLog);
+    else
+        hipLaunchKernelGGL((k_loc_decide<false>), dim3(1), dim3(kDecideThreads), 0, pf->stream, pf->ctl, pf->chunkSums,
+                           pf->chunkBase, pf->numChunks, pf->n, range, key_of(pf), pf->force, pf->branchLog);
     return check_launch("k_loc_decide");
 }
 
@@ -176,12 +188,14 @@ int launch_resample(pfx_loc* pf, float bx, float by, float bz, float range, floa
 {
     ProfScope ps(pf, PFX_K_RESAMPLE);
     const dim3 grid(pf->numTiles), block(kThreads);
+    StagePtrs st{};
+    for (int k = 0; k < 4; ++k) st.a[k] = pf->stageSlab ? pf->stageSlab + (size_t)k * pf->stageCap : nullptr;
     if (pf->recordAnc)
         hipLaunchKernelGGL((k_loc_resample<true>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->chunkBase, pf->tileIncl,
-                           pf->rsPart, pf->anc, pf->numTiles, pf->n, key_of(pf), bx, by, bz, range, stdRange);
+                           pf->rsPart, pf->anc, pf->numTiles, pf->n, st, key_of(pf), bx, by, bz, range, stdRange);
     else
         hipLaunchKernelGGL((k_loc_resample<false>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->chunkBase, pf->tileIncl,
-                           pf->rsPart, (int*)nullptr, pf->numTiles, pf->n, key_of(pf), bx, by, bz, range, stdRange);
+                           pf->rsPart, (int*)nullptr, pf->numTiles, pf->n, st, key_of(pf), bx, by, bz, range, stdRange);
     return check_launch("k_loc_resample");
 }
 
@@ -190,7 +204,7 @@ int launch_spawn(pfx_loc* pf, float bx, float by, float bz, float range, float s
     if (launch_set_ctl(pf, 0, 1, 1.0f, 0)) return -1;
     ProfScope ps(pf, PFX_K_SPAWN);
     hipLaunchKernelGGL(k_loc_spawn, dim3(pf->numTiles), dim3(kThreads), 0, pf->stream, pf->bufs, pf->ctl, pf->rsPart, pf->n,
-                       key_of(pf), bx, by, bz, range, stdRange);
+                       pf->selfBegin, key_of(pf), bx, by, bz, range, stdRange);
     return check_launch("k_loc_spawn");
 }
 
@@ -226,6 +240,10 @@ void free_device(pfx_loc* pf)
     if (pf->branchLog) hipFree(pf->branchLog);
     if (pf->ctl) hipFree(pf->ctl);
     if (pf->hostCtl) hipHostFree(pf->hostCtl);
+    if (pf->stageSlab) hipFree(pf->stageSlab);
+    if (pf->dAll) hipFree(pf->dAll);
+    if (pf->dPlan) hipFree(pf->dPlan);
+    if (pf->hostPlan) hipHostFree(pf->hostPlan);
     for (auto& r : pf->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     pf->prof.clear();
     if (pf->ownStream && pf->stream) hipStreamDestroy(pf->stream);
@@ -289,6 +307,7 @@ extern "C" pfx_loc* pfx_loc_create(int64_t n, uint32_t seed, uint32_t stream_id,
     pf->numChunks = (pf->numTiles + kChunkTiles - 1) / kChunkTiles;
     pf->seed = seed;
     pf->streamId = stream_id;
+    pf->nGlobal = n;
     DeviceGuard g(device);
     if (alloc_device(pf)) { free_device(pf); delete pf; return nullptr; }
     std::lock_guard<std::mutex> lk(g_mu);
@@ -385,6 +404,8 @@ extern "C" int pfx_loc_deposit_rssi(pfx_loc* pf, float bx, float by, float bz, i
     return pfx_loc_deposit_range(pf, bx, by, bz, 1.5f, 0.5f);
 }
 
+extern "C" int pfx_loc_pose_from_sums(pfx_loc* pf, const double p[6], double* t, float* x, float* y, float* z, float* theta);
+
 extern "C" int pfx_loc_get_tag_loc(pfx_loc* pf, double* t, float* x, float* y, float* z, float* theta)
 {   // particleFilter.c:248-291
     clear_error();
@@ -400,19 +421,7 @@ extern "C" int pfx_loc_get_tag_loc(pfx_loc* pf, double* t, float* x, float* y, f
         if (read_ctl(pf)) return -1;
         pf->poseDirty = false;
     }
-    const double* p = pf->hostCtl->pose;
-    const float s = (float)p[0], xs = (float)p[1], ys = (float)p[2], zs = (float)p[3], cs = (float)p[4], sn = (float)p[5];
-    *t = pf->vio.lastT;
-    *x = xs / s;
-    *y = ys / s;
-    *z = zs / s;
-    *theta = atan2f(sn, cs);
-    const float dx = pf->vio.lastX - pf->vio.firstX, dy = pf->vio.lastY - pf->vio.firstY, dz = pf->vio.lastZ - pf->vio.firstZ;
-    const float co = cosf(*theta), si = sinf(*theta);
-    *x += dx * co - dy * si;
-    *y += dx * si + dy * co;
-    *z += dz;
-    return 1;
+    return pfx_loc_pose_from_sums(pf, pf->hostCtl->pose, t, x, y, z, theta);
 }
 
 // ------------------------------------------------------------------ state access
@@ -567,6 +576,155 @@ extern "C" int pfx_resample_indices_f32(const float* cdf, int64_t n, float rStar
 extern "C" int pfx_resample_indices_f64(const double* cdf, int64_t n, double rStart, double rStep, int32_t* anc, int device)
 {
     return resample_indices_impl<double>(cdf, n, rStart, rStep, anc, device);
+}
+
+// ------------------------------------------------------------------ one filter sharded over several GPUs
+// The host side (slam3d_amd/sharded.py) owns the collectives; these entry points are the local halves of a
+// deposit.  Sequence per deposit on every rank:
+//   pfx_loc_shard_pass1   stream kernel + local prefix; the 8 local sums land in device memory
+//   (all-gather of the 8 doubles of every rank into pfx_loc_shard_all_ptr, by the caller, e.g. RCCL)
+//   pfx_loc_shard_decide  the global decision on the gathered sums, identical on every rank; returns the plan
+//   pfx_loc_shard_resample (if the plan says so) offspring of the local particles; those that belong to another
+//                         shard's index range are staged, the caller ships them (P2P) into the peers' arrays
+extern "C" int pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64_t n_global, int64_t self_begin,
+                                    int64_t stage_capacity)
+{
+    clear_error();
+    if (num_shards < 1 || num_shards > kMaxShards || rank < 0 || rank >= num_shards) {
+        set_error("pfx_loc_shard_config: rank %d / shards %d out of range (max %d)", rank, num_shards, kMaxShards);
+        return -2;
+    }
+    if (self_begin < 0 || self_begin + pf->n > n_global) { set_error("pfx_loc_shard_config: index range outside [0, n_global)"); return -2; }
+    DeviceGuard g(pf->device);
+    pf->rank = rank; pf->numShards = num_shards; pf->nGlobal = n_global; pf->selfBegin = self_begin;
+    if (!pf->dAll) {
+        PF_HIP_OK(hipMalloc((void**)&pf->dAll, kMaxShards * 8 * sizeof(double)));
+        PF_HIP_OK(hipMalloc((void**)&pf->dPlan, sizeof(ShardPlan)));
+        PF_HIP_OK(hipHostMalloc((void**)&pf->hostPlan, sizeof(ShardPlan), hipHostMallocDefault));
+    }
+    if (stage_capacity > 0 && (size_t)stage_capacity != pf->stageCap) {
+        if (pf->stageSlab) { PF_HIP_OK(hipStreamSynchronize(pf->stream)); hipFree(pf->stageSlab); pf->stageSlab = nullptr; }
+        pf->stageCap = (size_t)stage_capacity;
+        PF_HIP_OK(hipMalloc((void**)&pf->stageSlab, pf->stageCap * 4 * sizeof(float)));
+    }
+    return 0;
+}
+
+// returns 1 if the filter was not initialised and has now been spawned (no decision follows), 0 otherwise
+extern "C" int pfx_loc_shard_pass1(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    float d[5];
+    pf->epoch++;
+    vio_commit(pf->vio, d);
+    pf->poseDirty = true;
+    if (!pf->initialized) {
+        if (launch_spawn(pf, bx, by, bz, range, stdRange)) return -1;
+        pf->initialized = true;
+        return 1;
+    }
+    if (launch_stream(pf, !is_zero_motion(d), true, motion_of(d), gate_of(bx, by, bz, range, stdRange))) return -1;
+    if (launch_decide(pf, range, true)) return -1;
+    return 0;
+}
+
+extern "C" void* pfx_loc_shard_local_ptr(pfx_loc* pf) { return (void*)pf->ctl->local; }   // device address, 8 doubles
+extern "C" void* pfx_loc_shard_all_ptr(pfx_loc* pf) { return (void*)pf->dAll; }           // device, kMaxShards*8 doubles
+
+// out_F: num_shards + 1 global offspring boundaries (meaningful when *out_branch == 1)
+extern "C" int pfx_loc_shard_decide(pfx_loc* pf, float range, int* out_branch, int64_t* out_F)
+{
+    clear_error();
+    if (!pf->dAll) { set_error("pfx_loc_shard_decide: call pfx_loc_shard_config first"); return -2; }
+    DeviceGuard g(pf->device);
+    {
+        ProfScope ps(pf, PFX_K_DECIDE);
+        hipLaunchKernelGGL(k_loc_shard_decide, dim3(1), dim3(64), 0, pf->stream, pf->ctl, pf->dAll, pf->numShards, pf->rank,
+                           pf->nGlobal, pf->selfBegin, pf->selfBegin + pf->n, range, key_of(pf), pf->force, pf->branchLog,
+                           pf->dPlan);
+        if (check_launch("k_loc_shard_decide")) return -1;
+    }
+    PF_HIP_OK(hipMemcpyAsync(pf->hostPlan, pf->dPlan, sizeof(ShardPlan), hipMemcpyDeviceToHost, pf->stream));
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    *out_branch = pf->hostPlan->branch;
+    for (int k = 0; k <= pf->numShards; ++k) out_F[k] = pf->hostPlan->F[k];
+    return 0;
+}
+
+extern "C" int pfx_loc_shard_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    if (pf->hostPlan && pf->hostPlan->branch == 1) {
+        const long long ob = pf->hostPlan->F[pf->rank], oe = pf->hostPlan->F[pf->rank + 1];
+        const long long sb = pf->selfBegin, se = pf->selfBegin + pf->n;
+        const long long below = sb > ob ? (sb < oe ? sb : oe) - ob : 0;
+        const long long above = oe > se ? oe - (se > ob ? se : ob) : 0;
+        if ((size_t)(below + above) > pf->stageCap) {
+            set_error("pfx_loc_shard_resample: %lld offspring belong to other shards but the staging area holds %zu "
+                      "(shard imbalance beyond the configured slack)", below + above, pf->stageCap);
+            return -3;
+        }
+    }
+    return launch_resample(pf, bx, by, bz, range, stdRange);
+}
+
+// device pointers: the staging arrays (x,y,z,theta) and the CURRENT particle arrays (w,x,y,z,theta).  After a
+// resampling decision "current" is the buffer the offspring are written to.  Uses the host copy of the plan.
+extern "C" int pfx_loc_shard_ptrs(pfx_loc* pf, void* stage[4], void* current[5])
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    if (read_ctl(pf)) return -1;
+    for (int k = 0; k < 4; ++k) stage[k] = pf->stageSlab ? (void*)(pf->stageSlab + (size_t)k * pf->stageCap) : nullptr;
+    for (int k = 0; k < 5; ++k) current[k] = pf->bufs.a[pf->hostCtl->cur][k];
+    return 0;
+}
+
+// w[begin, begin+count) = 1 in the current buffer: the weights of offspring received from other shards
+extern "C" int pfx_loc_shard_fill_w(pfx_loc* pf, int cur, int64_t begin, int64_t count)
+{
+    clear_error();
+    if (count <= 0) return 0;
+    if (begin < 0 || begin + count > pf->n || cur < 0 || cur > 1) { set_error("pfx_loc_shard_fill_w: range outside the shard"); return -2; }
+    DeviceGuard g(pf->device);
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, pf->stream, pf->bufs.a[cur][0] + begin, 1.0f,
+                       (long long)count);
+    return check_launch("k_fill");
+}
+
+// local pose sums {sum w, w x, w y, w z, w cos, w sin} of the particles this shard produced / holds
+extern "C" int pfx_loc_shard_pose_sums(pfx_loc* pf, double out[6])
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    {
+        ProfScope ps(pf, PFX_K_POSE);
+        hipLaunchKernelGGL(k_loc_pose, dim3(1), dim3(kThreads), 0, pf->stream, pf->ctl, pf->tileSums, pf->rsPart, pf->numTiles, pf->n);
+        if (check_launch("k_loc_pose")) return -1;
+    }
+    if (read_ctl(pf)) return -1;
+    for (int k = 0; k < 6; ++k) out[k] = pf->hostCtl->pose[k];
+    return 0;
+}
+
+// particleFilter.c:274-290 on given (global) pose sums: mean, circular mean, plus the uncommitted VIO delta
+extern "C" int pfx_loc_pose_from_sums(pfx_loc* pf, const double p[6], double* t, float* x, float* y, float* z, float* theta)
+{
+    if (!pf->initialized) return 0;
+    const float s = (float)p[0], xs = (float)p[1], ys = (float)p[2], zs = (float)p[3], cs = (float)p[4], sn = (float)p[5];
+    *t = pf->vio.lastT;
+    *x = xs / s;
+    *y = ys / s;
+    *z = zs / s;
+    *theta = atan2f(sn, cs);
+    const float dx = pf->vio.lastX - pf->vio.firstX, dy = pf->vio.lastY - pf->vio.firstY, dz = pf->vio.lastZ - pf->vio.firstZ;
+    const float co = cosf(*theta), si = sinf(*theta);
+    *x += dx * co - dy * si;
+    *y += dx * si + dy * co;
+    *z += dz;
+    return 1;
 }
 
 // ------------------------------------------------------------------ kernel timing

@@ -41,6 +41,21 @@ struct LocCtl {
     double rStart, rStep;
     double pose[6];     // sum w, w*x, w*y, w*z, w*cos, w*sin of the current particles
     long long nDecisions;   // deposits decided so far (index into the branch log)
+    // Span of this filter inside a (possibly larger, sharded) global filter.  Unsharded: [0,S) x [0,n).
+    double shardBase, shardEnd;     // CDF values at the first / past the last local particle
+    long long outBegin, outEnd;     // global offspring indices produced from the local particles
+    long long selfBegin, selfEnd;   // global indices of the particles this shard holds (targets kept locally)
+    long long nGlobal;
+    double local[8];                // sharded: the local sums handed to the all-gather (s ss c sn wx wy wz 0)
+};
+
+// What a shard's host needs to know after a sharded decision (copied back once per deposit).
+constexpr int kMaxShards = 16;
+struct ShardPlan {
+    int branch, numSpawn;
+    float htheta, wscale;
+    double S, rStart, rStep;
+    long long F[kMaxShards + 1];    // F[g] = first global offspring index produced by shard g; F[G] = nGlobal
 };
 
 constexpr int kBranchLogSize = 65536;
@@ -51,14 +66,18 @@ struct Gate { float bx, by, bz, range, thresh, minWeight; };
 constexpr int kSumsPerTile = 8;     // s ss c sn wx wy wz (pad)
 constexpr int kRsPerTile = 8;       // x y z c sn count (pad)
 constexpr int kChunkTiles = 256;    // tiles per chunk of the two-level prefix
-constexpr int kMaxChunks = 8192;    // 8192 * 256 * 1024 = 2^31 particles
+constexpr int kMaxChunks = 1024;    // one chunk per thread of k_loc_decide: 1024 * 256 * 1024 = 2^28 particles
+
+__device__ __forceinline__ long long first_offspring_at(double b, double rStart, double rStep, long long n);
 
 // ------------------------------------------------------------------ streaming pass
 template <bool MOTION, bool GATE>
 __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const LocCtl* __restrict__ ctl,
-                                                        double* __restrict__ tileSums, long long n,
+                                                        double* __restrict__ tileSums, long long n, long long idx0,
                                                         RngKey key, Motion mo, Gate ga)
 {
+    // idx0: global index of local particle 0 (0 unless the filter is one shard of a larger one); the
+    // Philox counter uses the global index, so the noise does not depend on how the filter is sharded
     __shared__ double red[4 * 7];
     const int cur = ctl->cur;
     const float wscale = ctl->wscale;
@@ -90,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
             sincosf(thi, &s0, &c0);
             const float pDx = mo.dx * c0 - mo.dy * s0;
             const float pDy = mo.dx * s0 + mo.dy * c0;
-            const u32x4 r = rng_block(key, P_VIO, (uint64_t)i, 0);
+            const u32x4 r = rng_block(key, P_VIO, (uint64_t)(idx0 + i), 0);
             float rx, ry, rz, rth;
             normal2(r.a, r.b, rx, ry);
             normal2(r.c, r.d, rz, rth);
@@ -188,7 +207,50 @@ __device__ __forceinline__ double block1024_sum(double v, double* lds16)
     return t;       // every thread gets the same total
 }
 
-// force: -1 follow the reference's test, 0 never resample, 1 always resample (worst-case traffic runs)
+// The scalar part of pfResample.c:51-68,80 on the global totals tot[7] = {S, SS, C, SN, WX, WY, WZ} of n
+// particles: ESS / respawn test, heading bandwidth, rStart, or the deferred normalisation factor.
+// force: -1 follow the reference's test, 0 never resample, 1 always resample (worst-case traffic runs).
+__device__ __forceinline__ bool decide_scalars(LocCtl* __restrict__ ctl, const double (&tot)[7], long long n, float range,
+                                               const RngKey& key, int force, unsigned char* __restrict__ branchLog)
+{
+    const double S = tot[0];
+    const int cur = ctl->cur;
+    // pfResample.c:51-58 on the float-rounded totals
+    const float s = (float)S, ss = (float)tot[1];
+    float csum = (float)tot[2], ssum = (float)tot[3];
+    const float ess = s * s / ss;
+    const float invN = 1.0f / (float)n;
+    int numSpawn = 0;
+    if (s * invN < kWeightSpawnThresh && range < kRadiusSpawnThresh) numSpawn = (int)lroundf((float)n * kPctSpawn);
+    bool resample = (ess * invN < kResampleThresh) || numSpawn > 0;
+    if (force >= 0) resample = force != 0;
+    ctl->s = s; ctl->ss = ss; ctl->csum = csum; ctl->ssum = ssum; ctl->ess = ess; ctl->S = S;
+    ctl->numSpawn = numSpawn;
+    if (resample) {
+        // pfResample.c:60-68
+        csum /= s;
+        ssum /= s;
+        float h = csum * csum + ssum * ssum;
+        h = h > 1e-10f ? h : 1e-10f;
+        h = h < 1.0f - 1e-10f ? h : 1.0f - 1e-10f;
+        h = sqrtf(-logf(h) / ess);
+        const double rStep = S / (double)n;
+        const double rStart = (double)uniform01(rng_block(key, P_RSTART, 0, 0).a) * rStep;
+        ctl->htheta = h; ctl->rStep = rStep; ctl->rStart = rStart;
+        ctl->src = cur; ctl->dst = cur ^ 1; ctl->cur = cur ^ 1;
+        ctl->wscale = 1.0f; ctl->m = 0.0f; ctl->branch = 1;
+    } else {
+        // pfResample.c:80-82, deferred: the next reader multiplies w by m
+        const float m = (float)n / s;
+        ctl->wscale = m; ctl->m = m; ctl->branch = 0; ctl->htheta = 0.0f;
+    }
+    const long long k = ctl->nDecisions;
+    branchLog[k % kBranchLogSize] = resample ? 1 : 0;
+    ctl->nDecisions = k + 1;
+    return resample;
+}
+
+template <bool LOCAL_ONLY>
 __global__ __launch_bounds__(kDecideThreads) void k_loc_decide(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
                                                               double* __restrict__ chunkBase, int numChunks, long long n,
                                                               float range, RngKey key, int force,
@@ -242,56 +304,84 @@ __global__ __launch_bounds__(kDecideThreads) void k_loc_decide(LocCtl* __restric
     for (int k = 1; k < 7; ++k) tot[k] = block1024_sum(loc[k], lds16);
     __syncthreads();
 
+    if (LOCAL_ONLY) {
+        // sharded filter: publish the local sums; the decision is taken after the all-gather
+        if (tid == 0) {
+            ctl->local[0] = shS;
+#pragma unroll
+            for (int k = 1; k < 7; ++k) ctl->local[k] = tot[k];
+            ctl->local[7] = 0.0;
+        }
+        return;
+    }
     if (tid == 0) {
-        const double S = shS;
-        const int cur = ctl->cur;
-        // pfResample.c:51-58 on the float-rounded totals
-        const float s = (float)S, ss = (float)tot[1];
-        float csum = (float)tot[2], ssum = (float)tot[3];
-        const float ess = s * s / ss;
-        const float invN = 1.0f / (float)n;
-        int numSpawn = 0;
-        if (s * invN < kWeightSpawnThresh && range < kRadiusSpawnThresh) numSpawn = (int)lroundf((float)n * kPctSpawn);
-        bool resample = (ess * invN < kResampleThresh) || numSpawn > 0;
-        if (force >= 0) resample = force != 0;
-        ctl->s = s; ctl->ss = ss; ctl->csum = csum; ctl->ssum = ssum; ctl->ess = ess; ctl->S = S;
-        ctl->numSpawn = numSpawn;
-        if (resample) {
-            // pfResample.c:60-68
-            csum /= s;
-            ssum /= s;
-            float h = csum * csum + ssum * ssum;
-            h = h > 1e-10f ? h : 1e-10f;
-            h = h < 1.0f - 1e-10f ? h : 1.0f - 1e-10f;
-            h = sqrtf(-logf(h) / ess);
-            const double rStep = S / (double)n;
-            const double rStart = (double)uniform01(rng_block(key, P_RSTART, 0, 0).a) * rStep;
-            ctl->htheta = h; ctl->rStep = rStep; ctl->rStart = rStart;
-            ctl->src = cur; ctl->dst = cur ^ 1; ctl->cur = cur ^ 1;
-            ctl->wscale = 1.0f; ctl->m = 0.0f; ctl->branch = 1;
-        } else {
-            // pfResample.c:80-82, deferred: the next reader multiplies w by m
-            const float m = (float)n / s;
-            ctl->wscale = m; ctl->m = m; ctl->branch = 0; ctl->htheta = 0.0f;
-            ctl->pose[0] = S; ctl->pose[1] = tot[4]; ctl->pose[2] = tot[5]; ctl->pose[3] = tot[6];
+        tot[0] = shS;
+        const bool resample = decide_scalars(ctl, tot, n, range, key, force, branchLog);
+        if (!resample) {    // the streaming pass's sums are the pose sums of the (unnormalised) current particles
+            ctl->pose[0] = tot[0]; ctl->pose[1] = tot[4]; ctl->pose[2] = tot[5]; ctl->pose[3] = tot[6];
             ctl->pose[4] = tot[2]; ctl->pose[5] = tot[3];
         }
-        const long long k = ctl->nDecisions;
-        branchLog[k % kBranchLogSize] = resample ? 1 : 0;
-        ctl->nDecisions = k + 1;
+        ctl->shardBase = 0.0; ctl->shardEnd = tot[0];
+        ctl->outBegin = 0; ctl->outEnd = n; ctl->selfBegin = 0; ctl->selfEnd = n; ctl->nGlobal = n;
     }
+}
+
+// Sharded filter, after the all-gather of every shard's local sums (all[g*8 + k], g in rank order): the same
+// decision on the GLOBAL totals, taken identically by every shard (same inputs, same order of additions), plus
+// this shard's span of the global CDF and the first offspring index of every shard.  One thread.
+__global__ void k_loc_shard_decide(LocCtl* __restrict__ ctl, const double* __restrict__ all, int numShards, int rank,
+                                   long long nGlobal, long long selfBegin, long long selfEnd, float range, RngKey key,
+                                   int force, unsigned char* __restrict__ branchLog, ShardPlan* __restrict__ plan)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double tot[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    double base[kMaxShards + 1];
+    base[0] = 0.0;
+    for (int g = 0; g < numShards; ++g) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) tot[k] += all[g * 8 + k];
+        base[g + 1] = tot[0];                       // sequential prefix: non-decreasing, base[G] == S exactly
+    }
+    const bool resample = decide_scalars(ctl, tot, nGlobal, range, key, force, branchLog);
+    if (!resample) {    // local part of the pose sums; the host all-reduces them when a pose is asked for
+        const double* l = ctl->local;
+        ctl->pose[0] = l[0]; ctl->pose[1] = l[4]; ctl->pose[2] = l[5]; ctl->pose[3] = l[6]; ctl->pose[4] = l[2]; ctl->pose[5] = l[3];
+    }
+    const double rStart = ctl->rStart, rStep = ctl->rStep;
+    plan->branch = resample ? 1 : 0;
+    plan->numSpawn = ctl->numSpawn; plan->htheta = ctl->htheta; plan->wscale = ctl->wscale;
+    plan->S = tot[0]; plan->rStart = rStart; plan->rStep = rStep;
+    for (int g = 0; g <= numShards; ++g) {
+        long long f = 0;
+        if (resample) f = (g == 0) ? 0 : (g == numShards ? nGlobal : first_offspring_at(base[g], rStart, rStep, nGlobal));
+        plan->F[g] = f;
+    }
+    ctl->shardBase = base[rank]; ctl->shardEnd = base[rank + 1];
+    ctl->outBegin = plan->F[rank]; ctl->outEnd = plan->F[rank + 1];
+    ctl->selfBegin = selfBegin; ctl->selfEnd = selfEnd; ctl->nGlobal = nGlobal;
+}
+
+__global__ void k_fill(float* __restrict__ p, float v, long long count)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = v;
 }
 
 // CDF value at the START of tile t (t in [0, numTiles]).  The same expression is evaluated by the
 // workgroups on both sides of a boundary, and it is non-decreasing in t: inside a chunk tileIncl is
 // non-decreasing and the sum is capped by the next chunk's base.
-__device__ __forceinline__ double tile_start_cdf(const double* __restrict__ chunkBase, const double* __restrict__ tileIncl, int t)
+__device__ __forceinline__ double tile_start_cdf(const double* __restrict__ chunkBase, const double* __restrict__ tileIncl, int t,
+                                                 double shardBase, double shardEnd)
 {
     const int c = t / kChunkTiles;
-    if (t % kChunkTiles == 0) return chunkBase[c];
-    const double v = chunkBase[c] + tileIncl[t - 1];
-    const double cap = chunkBase[c + 1];
-    return v < cap ? v : cap;
+    double v = chunkBase[c];
+    if (t % kChunkTiles != 0) {
+        v += tileIncl[t - 1];
+        const double cap = chunkBase[c + 1];
+        v = v < cap ? v : cap;
+    }
+    v += shardBase;                         // local prefix -> position in the global CDF
+    return v < shardEnd ? v : shardEnd;
 }
 
 // Number of offspring i in [0,n) with rStart + rStep*i < b (u_i is non-decreasing in i), i.e. the first
@@ -308,13 +398,17 @@ __device__ __forceinline__ long long first_offspring_at(double b, double rStart,
 }
 
 // ------------------------------------------------------------------ resample
+// Staging arrays for offspring whose place is on another shard (sharded filters only; null otherwise):
+// x,y,z,theta of the offspring below this shard's own index range first, then those above it.
+struct StagePtrs { float* a[4]; };
+
 template <bool RECORD>
 __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const LocCtl* __restrict__ ctl,
                                                           const double* __restrict__ chunkBase,
                                                           const double* __restrict__ tileIncl,
                                                           double* __restrict__ rsPart, int* __restrict__ ancOut,
-                                                          int numTiles, long long n, RngKey key, float bx, float by, float bz,
-                                                          float range, float stdRange)
+                                                          int numTiles, long long n, StagePtrs stage, RngKey key,
+                                                          float bx, float by, float bz, float range, float stdRange)
 {
     if (ctl->branch != 1) return;           // normalise-only step: nothing to do (wave-uniform exit)
 
@@ -322,10 +416,15 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
     __shared__ double red[4 * 6];
     const int t = blockIdx.x, tid = threadIdx.x;
     const double rStart = ctl->rStart, rStep = ctl->rStep;
-    const double tileStart = tile_start_cdf(chunkBase, tileIncl, t);
-    const long long i0 = (t == 0) ? 0 : first_offspring_at(tileStart, rStart, rStep, n);
-    const long long i1 = (t == numTiles - 1) ? n
-                                             : first_offspring_at(tile_start_cdf(chunkBase, tileIncl, t + 1), rStart, rStep, n);
+    const double shardBase = ctl->shardBase, shardEnd = ctl->shardEnd;
+    const long long nGlobal = ctl->nGlobal;
+    // Offspring range of this tile.  Neighbouring workgroups (and neighbouring shards) evaluate the same
+    // expression for a shared boundary, so the ranges tile [outBegin, outEnd) exactly.
+    const double tileStart = tile_start_cdf(chunkBase, tileIncl, t, shardBase, shardEnd);
+    const long long i0 = (t == 0) ? ctl->outBegin : first_offspring_at(tileStart, rStart, rStep, nGlobal);
+    const long long i1 = (t == numTiles - 1)
+                             ? ctl->outEnd
+                             : first_offspring_at(tile_start_cdf(chunkBase, tileIncl, t + 1, shardBase, shardEnd), rStart, rStep, nGlobal);
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
 
     if (i0 < i1) {
@@ -358,6 +457,11 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
         const int nValid = rem < kTile ? (int)rem : kTile;
         const float hTheta = ctl->htheta;
         const int numSpawn = ctl->numSpawn;
+        const long long selfBegin = ctl->selfBegin, selfEnd = ctl->selfEnd, outBegin = ctl->outBegin;
+        const long long outEnd = ctl->outEnd;
+        // staged offspring: those below the shard's own range first, then those above it
+        const long long below = selfBegin > outBegin ? (selfBegin < outEnd ? selfBegin : outEnd) - outBegin : 0;
+        const long long aboveStart = selfEnd > outBegin ? selfEnd : outBegin;
 
         for (long long i = i0 + tid; i < i1; i += kThreads) {
             const double u = rStart + rStep * (double)i;        // pfResample.c:71
@@ -369,8 +473,14 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
             } else {
                 spawn_from_other(key, (uint64_t)i, sx[a], sy[a], sz[a], st[a], kHxyz, hTheta, x, y, z, th);
             }
-            dw[i] = 1.0f; dx[i] = x; dy[i] = y; dz[i] = z; dt[i] = th;
-            if (RECORD) ancOut[i] = (int)a;
+            if (i >= selfBegin && i < selfEnd) {
+                const long long p = i - selfBegin;
+                dw[p] = 1.0f; dx[p] = x; dy[p] = y; dz[p] = z; dt[p] = th;
+                if (RECORD) ancOut[p] = (int)a;
+            } else {
+                const long long p = (i < selfBegin) ? i - outBegin : (i - aboveStart) + below;
+                stage.a[0][p] = x; stage.a[1][p] = y; stage.a[2][p] = z; stage.a[3][p] = th;
+            }
             float sn, cs;
             sincosf(th, &sn, &cs);
             acc[0] += x; acc[1] += y; acc[2] += z; acc[3] += cs; acc[4] += sn; acc[5] += 1.0;
@@ -387,7 +497,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
 
 // ------------------------------------------------------------------ initial spawn (pfInit.c:20-25)
 __global__ __launch_bounds__(kThreads) void k_loc_spawn(LocBufs bufs, LocCtl* __restrict__ ctl, double* __restrict__ rsPart,
-                                                       long long n, RngKey key, float bx, float by, float bz,
+                                                       long long n, long long idx0, RngKey key, float bx, float by, float bz,
                                                        float range, float stdRange)
 {
     __shared__ double red[4 * 6];
@@ -404,7 +514,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_spawn(LocBufs bufs, LocCtl* __
         const long long i = tbase + k * kThreads + threadIdx.x;
         if (i < n) {
             float x, y, z, th;
-            spawn_from_range(key, (uint64_t)i, bx, by, bz, range, stdRange, x, y, z, th);
+            spawn_from_range(key, (uint64_t)(idx0 + i), bx, by, bz, range, stdRange, x, y, z, th);
             pw[i] = 1.0f; px[i] = x; py[i] = y; pz[i] = z; pt[i] = th;
             float sn, cs;
             sincosf(th, &sn, &cs);

@@ -1,0 +1,316 @@
+"""One particleFilterLoc sharded by particle range over the GPUs of a node (BASELINE.json configs[3]).
+
+No counterpart in the reference (it has no parallelism of any kind); the interface is
+still the wrapper's (depositVio / depositRange / depositRssi / getTagLoc), so the same drivers run it.
+
+Rank g holds the global particles [T_g, T_{g+1}), T_g = floor(g*N/G).  Per deposit:
+
+  1. local streaming pass (VIO + gate + sums) and local tile prefix            -- no communication
+  2. all-gather of 8 doubles per rank (sum w, w^2, w cos, w sin, w x, w y, w z) -- RCCL, latency-bound
+  3. every rank takes the SAME decision from the gathered sums (same order of additions), and derives
+     its span [base_g, base_{g+1}) of the global CDF and the global offspring range [F_g, F_{g+1}) its
+     particles produce.  rStart comes from Philox(epoch), identical everywhere: no broadcast.
+  4. on a resampling step each rank resamples its own ancestors.  Offspring whose index falls in the
+     rank's own range are written in place; the others are staged and shipped point-to-point (xGMI) straight
+     into the owner's arrays, so every shard ends the step with exactly T_{g+1}-T_g particles again.
+     Particle noise is keyed by GLOBAL index, so the result does not depend on the number of shards.
+
+A non-resampling step moves no particle data at all.  The pose query all-reduces 6 doubles.
+
+`backend` is the local half: `GpuShard` (libparticlefilter.so) in production; the tests plug an
+oracle-backed CPU stand-in with the same methods to exercise this host logic under gloo.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+MAX_SHARDS = 16
+
+
+def shard_bounds(n_total: int, world: int) -> List[int]:
+    """T_0..T_G: equal split, remainder spread by floor(g*N/G)."""
+    return [(g * n_total) // world for g in range(world + 1)]
+
+
+def overlap(a0: int, a1: int, b0: int, b1: int) -> Tuple[int, int]:
+    lo, hi = max(a0, b0), min(a1, b1)
+    return (lo, hi) if hi > lo else (lo, lo)
+
+
+def exchange_plan(F: Sequence[int], T: Sequence[int], rank: int):
+    """Who sends what after a resampling decision.
+
+    F[g]..F[g+1] = global offspring indices produced by rank g; T[g]..T[g+1] = indices rank g holds.
+    Returns (sends, recvs, below): sends = [(peer, stage_offset, count)], recvs = [(peer, local_offset, count)],
+    below = number of staged offspring that precede this rank's own range (the stage holds those first, then
+    the ones above the range -- the layout k_loc_resample writes)."""
+    G = len(T) - 1
+    ob, oe = F[rank], F[rank + 1]
+    sb, se = T[rank], T[rank + 1]
+    below = max(0, min(sb, oe) - ob)
+    sends, recvs = [], []
+    for h in range(G):
+        if h == rank:
+            continue
+        lo, hi = overlap(ob, oe, T[h], T[h + 1])
+        if hi > lo:
+            off = (lo - ob) if h < rank else (lo - max(se, ob)) + below
+            sends.append((h, off, hi - lo))
+        lo, hi = overlap(F[h], F[h + 1], sb, se)
+        if hi > lo:
+            recvs.append((h, lo - sb, hi - lo))
+    return sends, recvs, below
+
+
+# ------------------------------------------------------------------ the GPU backend
+class _DevMem:
+    """zero-copy view of library-owned device memory for torch (CUDA array interface)"""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class GpuShard:
+    """The local half of a sharded filter on one GPU (pfx_loc_shard_*, include/pfx.h)."""
+
+    def __init__(self, n_local: int, n_global: int, self_begin: int, rank: int, world: int, seed: int,
+                 device: int, stage_capacity: int):
+        import torch
+        from . import _lib
+        self._torch = torch
+        self._lib = _lib
+        self._L = _lib.lib()
+        self.n, self.device = int(n_local), int(device)
+        self._h = self._L.pfx_loc_create(self.n, seed & 0xFFFFFFFF, 0, self.device)
+        if not self._h:
+            raise _lib.PfxError(f"pfx_loc_create: {_lib.last_error()}")
+        self.stage_capacity = int(stage_capacity)
+        _lib.check(self._L.pfx_loc_shard_config(self._h, rank, world, n_global, self_begin, self.stage_capacity),
+                   "pfx_loc_shard_config")
+        self.world = world
+        # run the library's kernels on torch's current stream so that they are ordered with the collectives
+        self._L.pfx_loc_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        dev = f"cuda:{self.device}"
+        self._local = torch.as_tensor(_DevMem(self._L.pfx_loc_shard_local_ptr(self._h), 8, "<f8"), device=dev)
+        self._all = torch.as_tensor(_DevMem(self._L.pfx_loc_shard_all_ptr(self._h), MAX_SHARDS * 8, "<f8"), device=dev)
+        self._cur = 0
+        self._refresh_views()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pfx_loc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _refresh_views(self):
+        torch = self._torch
+        st, cur = (C.c_void_p * 4)(), (C.c_void_p * 5)()
+        self._lib.check(self._L.pfx_loc_shard_ptrs(self._h, st, cur), "pfx_loc_shard_ptrs")
+        dev = f"cuda:{self.device}"
+        self._stage = [torch.as_tensor(_DevMem(p, self.stage_capacity, "<f4"), device=dev) if p else None for p in st]
+        self._curr = [torch.as_tensor(_DevMem(p, self.n, "<f4"), device=dev) for p in cur]
+
+    # -- VIO bookkeeping and control are the library's
+    def deposit_vio(self, t, x, y, z, dist):
+        self._L.pfx_loc_deposit_vio(self._h, t, x, y, z, dist)
+
+    def set_force_branch(self, force):
+        self._L.pfx_loc_set_force_branch(self._h, int(force))
+
+    # -- the local halves of a deposit
+    def pass1(self, bx, by, bz, rng, std) -> int:
+        return self._lib.check(self._L.pfx_loc_shard_pass1(self._h, bx, by, bz, rng, std), "pfx_loc_shard_pass1")
+
+    def local_sums(self):
+        return self._local
+
+    def all_sums(self):
+        return self._all[: self.world * 8]
+
+    def decide(self, rng) -> Tuple[int, List[int]]:
+        br = C.c_int()
+        F = (C.c_int64 * (MAX_SHARDS + 1))()
+        self._lib.check(self._L.pfx_loc_shard_decide(self._h, rng, C.byref(br), F), "pfx_loc_shard_decide")
+        return br.value, [int(F[k]) for k in range(self.world + 1)]
+
+    def resample(self, bx, by, bz, rng, std):
+        self._lib.check(self._L.pfx_loc_shard_resample(self._h, bx, by, bz, rng, std), "pfx_loc_shard_resample")
+        self._refresh_views()       # the offspring buffer is now the current one
+
+    def stage_views(self, off, count):
+        return [s[off: off + count] for s in self._stage]
+
+    def current_views(self, off, count):
+        """x, y, z, theta slices of the current arrays"""
+        return [a[off: off + count] for a in self._curr[1:]]
+
+    def fill_w(self, off, count):
+        self._curr[0][off: off + count].fill_(1.0)
+
+    def pose_sums(self):
+        out = (C.c_double * 6)()
+        self._lib.check(self._L.pfx_loc_shard_pose_sums(self._h, out), "pfx_loc_shard_pose_sums")
+        return np.array(list(out), dtype=np.float64)
+
+    def pose_from_sums(self, sums):
+        arr = (C.c_double * 6)(*[float(v) for v in sums])
+        t = C.c_double()
+        x, y, z, th = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        ok = self._L.pfx_loc_pose_from_sums(self._h, arr, C.byref(t), C.byref(x), C.byref(y), C.byref(z), C.byref(th))
+        return (int(ok), t.value, np.float32(x.value), np.float32(y.value), np.float32(z.value), np.float32(th.value))
+
+    def download(self):
+        out = [np.empty(self.n, dtype=np.float32) for _ in range(5)]
+        self._lib.check(self._L.pfx_loc_download(self._h, *[a.ctypes.data_as(C.c_void_p) for a in out], self.n),
+                        "pfx_loc_download")
+        return tuple(out)
+
+    # -- profiling passthrough (bench.py)
+    def profile_begin(self, max_records):
+        self._lib.check(self._L.pfx_loc_profile_begin(self._h, int(max_records)), "pfx_loc_profile_begin")
+
+    def profile_records(self, cap=1 << 16):
+        kind = np.empty(cap, dtype=np.int32)
+        ms = np.empty(cap, dtype=np.float32)
+        k = self._lib.check(self._L.pfx_loc_profile_records(self._h, kind.ctypes.data_as(C.c_void_p),
+                                                            ms.ctypes.data_as(C.c_void_p), cap), "pfx_loc_profile_records")
+        return kind[:k].copy(), ms[:k].copy()
+
+    def branch_log(self, cap=65536):
+        out = np.empty(cap, dtype=np.uint8)
+        total = C.c_int64()
+        k = self._lib.check(self._L.pfx_loc_branch_log(self._h, out.ctypes.data_as(C.c_void_p), cap, C.byref(total)),
+                            "pfx_loc_branch_log")
+        return out[:k].copy(), int(total.value)
+
+
+# ------------------------------------------------------------------ the sharded filter
+class ShardedLocFilter:
+    """particleFilterLoc of n_total particles over all ranks of a torch.distributed process group."""
+
+    def __init__(self, n_total: int, seed: int = 0, device: int = 0, group=None, backend_factory=None,
+                 stage_slack: float = 1.0):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        if self.world > MAX_SHARDS:
+            raise ValueError(f"at most {MAX_SHARDS} shards")
+        self.n_total = int(n_total)
+        self.T = shard_bounds(self.n_total, self.world)
+        n_local = self.T[self.rank + 1] - self.T[self.rank]
+        if n_local < 1:
+            raise ValueError("fewer particles than ranks")
+        cap = int(n_local * stage_slack) + 1024
+        if backend_factory is None:
+            self.shard = GpuShard(n_local, self.n_total, self.T[self.rank], self.rank, self.world, seed, device, cap)
+        else:
+            self.shard = backend_factory(n_local, self.n_total, self.T[self.rank], self.rank, self.world, seed, cap)
+        self.stage_capacity = cap
+        self._pg_is_nccl = dist.get_backend(group) == "nccl"
+        self.initialized = False
+        self.last_branch = None
+        self.last_F = None
+        self.exchanged_particles = 0
+
+    # -- collectives (device tensors go straight to RCCL; under gloo they are staged through the host)
+    def _all_gather(self, out_t, in_t):
+        dist, torch = self._dist, self._torch
+        if self._pg_is_nccl or not in_t.is_cuda:
+            dist.all_gather_into_tensor(out_t, in_t, group=self.group)
+        else:
+            h_in = in_t.cpu()
+            h_out = torch.empty(out_t.shape, dtype=out_t.dtype)
+            dist.all_gather_into_tensor(h_out, h_in, group=self.group)
+            out_t.copy_(h_out)
+
+    def _p2p(self, sends, recvs):
+        """sends/recvs: lists of (peer, [tensors])"""
+        dist, torch = self._dist, self._torch
+        if not sends and not recvs:
+            return
+        staged = not self._pg_is_nccl and any(t.is_cuda for _, ts in sends + recvs for t in ts)
+        ops, back = [], []
+        for peer, ts in recvs:
+            for t in ts:
+                if staged:
+                    h = torch.empty(t.shape, dtype=t.dtype)
+                    back.append((t, h))
+                    ops.append(dist.P2POp(dist.irecv, h, peer, group=self.group))
+                else:
+                    ops.append(dist.P2POp(dist.irecv, t, peer, group=self.group))
+        for peer, ts in sends:
+            for t in ts:
+                ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer, group=self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for t, h in back:
+            t.copy_(h)
+
+    # -- the wrapper interface
+    def depositVio(self, t, x, y, z, dist_):
+        self.shard.deposit_vio(t, x, y, z, dist_)
+
+    def depositRange(self, bx, by, bz, range, stdRange):        # noqa: A002
+        sh = self.shard
+        if sh.pass1(bx, by, bz, range, stdRange) == 1:
+            self.initialized = True             # first range: every shard spawned its own particles
+            return
+        self._all_gather(sh.all_sums(), sh.local_sums())
+        branch, F = sh.decide(range)
+        self.last_branch, self.last_F = branch, F
+        if not branch:
+            return
+        sends, recvs, _below = exchange_plan(F, self.T, self.rank)
+        staged = sum(c for _, _, c in sends)
+        if staged > self.stage_capacity:
+            raise RuntimeError(f"rank {self.rank}: {staged} offspring belong to other shards, staging holds "
+                               f"{self.stage_capacity} (raise stage_slack)")
+        sh.resample(bx, by, bz, range, stdRange)
+        self._p2p([(p, sh.stage_views(off, cnt)) for p, off, cnt in sends],
+                  [(p, sh.current_views(off, cnt)) for p, off, cnt in recvs])
+        for _p, off, cnt in recvs:
+            sh.fill_w(off, cnt)
+        self.exchanged_particles += staged
+
+    def depositRssi(self, bx, by, bz, rssi):
+        self.depositRange(bx, by, bz, 1.5, 0.5)        # particleFilter.c:213-226
+
+    def getTagLoc(self):
+        torch, dist = self._torch, self._dist
+        if not self.initialized:
+            return (0, 0.0, np.float32(0), np.float32(0), np.float32(0), np.float32(0))
+        sums = torch.from_numpy(self.shard.pose_sums())
+        if self._pg_is_nccl:
+            d = sums.cuda()
+            dist.all_reduce(d, group=self.group)
+            sums = d.cpu()
+        else:
+            dist.all_reduce(sums, group=self.group)
+        return self.shard.pose_from_sums(sums.numpy())
+
+    # -- passthroughs used by bench.py
+    def set_force_branch(self, force):
+        self.shard.set_force_branch(force)
+
+    def profile_begin(self, max_records):
+        self.shard.profile_begin(max_records)
+
+    def profile_records(self):
+        return self.shard.profile_records()
+
+    def branch_log(self):
+        return self.shard.branch_log()
+
+    def download_local(self):
+        return self.shard.download()

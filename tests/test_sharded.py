@@ -1,0 +1,119 @@
+"""The sharded single filter (slam3d_amd/sharded.py): host logic under gloo with world_size > 1.
+
+CPU tests (not gpu): ranks use the oracle-backed shard stand-in (tests/_oracle_shard.py); the sharded run must
+reproduce the UNSHARDED oracle filter (Philox, f64 rule) -- same branch per deposit, same particles in the same
+global order, same poses -- because noise is keyed by global particle index and the decision is taken on
+globally gathered sums.  Differences allowed: float64 sums associate differently across shards (~1e-16), which
+can move an ancestor index by one for an offspring that sits within that distance of a CDF step.
+
+GPU test (gpu): two ranks share cuda:0 (gloo, tensors staged through the host -- RCCL needs one GPU per rank and
+the test box has one), running the real GpuShard kernels, against the single-GPU filter.
+"""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import _synth  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "tools", "sharded_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, backend, n, steps, force=-1, timeout=300):
+    out = tempfile.mkdtemp(prefix="shard_")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), WORKER,
+           "--backend", backend, "--pg", "gloo", "--particles", str(n), "--steps", str(steps), "--force", str(force), "--out", out]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return [np.load(os.path.join(out, f"rank{k}.npz")) for k in range(world)]
+
+
+def _gather(shards):
+    return [np.concatenate([s[k] for s in shards]) for k in ("w", "x", "y", "z", "th")]
+
+
+def _compare(shards, ref_arrays, ref_poses, ref_branches, n, tol):
+    T = shards[0]["T"]
+    assert [int(s["w"].shape[0]) for s in shards] == [int(T[g + 1] - T[g]) for g in range(len(shards))]
+    for s in shards[1:]:
+        assert np.array_equal(s["poses"], shards[0]["poses"])           # every rank reports the same pose
+        assert np.array_equal(s["branches"], shards[0]["branches"])
+    assert np.array_equal(shards[0]["branches"][1:], ref_branches[1:])
+    assert np.abs(shards[0]["poses"][:, 2:] - ref_poses[:, 2:]).max() <= 1e-4
+    got = _gather(shards)
+    for k in range(5):
+        d = np.abs(got[k] - ref_arrays[k])
+        if k == 4:
+            d = np.minimum(d, np.abs(d - 6.2831855))
+        bad = int((d > tol).sum())
+        assert bad <= max(2, n // 5000), (k, bad, float(d.max()))
+
+
+def test_exchange_plan_is_a_partition():
+    from slam3d_amd.sharded import exchange_plan, shard_bounds
+    n = 1003
+    T = shard_bounds(n, 4)
+    for F in ([0, 100, 500, 900, n], [0, 0, 0, n, n], [0, 700, 800, 900, n], [0, 250, 501, 752, n]):
+        recv_total = [0] * 4
+        kept = [0] * 4
+        for g in range(4):
+            sends, recvs, below = exchange_plan(F, T, g)
+            own_lo, own_hi = max(F[g], T[g]), min(F[g + 1], T[g + 1])
+            kept[g] = max(0, own_hi - own_lo)
+            assert sum(c for _, _, c in sends) + kept[g] == F[g + 1] - F[g]
+            offs = sorted((o, c) for _, o, c in sends)
+            pos = 0
+            for o, c in offs:                                   # staged ranges are contiguous, in order
+                assert o == pos
+                pos += c
+            assert below == sum(c for p, _, c in sends if p < g)
+            for h, off, c in recvs:
+                recv_total[g] += c
+                sh, _, _ = exchange_plan(F, T, h)
+                assert any(p == g and cc == c for p, _, cc in sh)
+        for g in range(4):
+            assert kept[g] + recv_total[g] == T[g + 1] - T[g]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_oracle_matches_unsharded(ora, world):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import sharded_worker as W
+    n, steps = 6001, 14
+    o = ora.OracleLoc(n, rng_mode=ora.RNG_PHILOX, seed=123456789, acc=ora.ACC_F64)
+    branches = []
+    poses = W.drive(o, W.events(steps), lambda f: branches.append(int(f.last_stats()["branch"])))
+    shards = _run(world, "oracle", n, steps)
+    _compare(shards, [a.copy() for a in o.arrays()], poses, np.array(branches), n, tol=1e-6)
+    assert shards[0]["branches"][1:].max() == 1, "the scene must exercise the resampling exchange"
+    assert max(int(s["moved"][-1]) for s in shards) > 0, "no particle ever crossed a shard boundary"
+
+
+@pytest.mark.gpu
+def test_sharded_gpu_two_ranks_match_single_gpu():
+    from slam3d_amd import particlefilter as pfm
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import sharded_worker as W
+    n, steps = 300007, 14
+    g = pfm.DeviceParticleFilterLoc(n, seed=123456789)
+    branches = []
+    poses = W.drive(g, W.events(steps), lambda f: branches.append(int(f.last_stats()["branch"])))
+    ref = g.download()
+    shards = _run(2, "gpu", n, steps)
+    _compare(shards, ref, poses, np.array(branches), n, tol=1e-6)
+    assert max(int(s["moved"][-1]) for s in shards) > 0

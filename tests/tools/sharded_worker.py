@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""One rank of a sharded-filter test run (launched by torch.distributed.run from tests/test_sharded*.py).
+
+    sharded_worker.py --backend oracle|gpu --particles N --steps K --out DIR [--force F] [--pg gloo|nccl]
+
+Every rank drives the same event list through a ShardedLocFilter and saves its shard (w,x,y,z,theta), the
+poses after every deposit and the branch of every deposit to DIR/rank<r>.npz.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def events(n_steps):
+    import _synth
+    bx, truth, rng = _synth.synthetic_scene(n_steps)
+    ev = []
+    for k in range(n_steps):
+        ev.append(("vio", 10.0 + 0.1 * k, float(truth[k, 0]), float(truth[k, 1]), float(truth[k, 2]), 0.0))
+        b = k % 8
+        ev.append(("range", float(bx[b, 0]), float(bx[b, 1]), float(bx[b, 2]), float(rng[k, 0]), 0.1))
+        if k % 3 == 2:
+            b2 = (k + 1) % 8
+            ev.append(("rssi", float(bx[b2, 0]), float(bx[b2, 1]), float(bx[b2, 2]), -55))
+    return ev
+
+
+def drive(pf, evs, on_deposit=None):
+    poses = []
+    for e in evs:
+        if e[0] == "vio":
+            pf.depositVio(*e[1:])
+            continue
+        if e[0] == "range":
+            pf.depositRange(*e[1:])
+        else:
+            pf.depositRssi(*e[1:])
+        poses.append([float(v) for v in pf.getTagLoc()])
+        if on_deposit:
+            on_deposit(pf)
+    return np.array(poses)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="oracle")
+    ap.add_argument("--pg", default="gloo")
+    ap.add_argument("--particles", dest="n", type=int, default=20000)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--seed", type=int, default=123456789)
+    ap.add_argument("--force", type=int, default=-1)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if a.pg == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(a.pg)
+    from slam3d_amd.sharded import ShardedLocFilter
+    factory = None
+    if a.backend == "oracle":
+        from _oracle_shard import OracleShard
+        factory = OracleShard
+    dev = int(os.environ.get("LOCAL_RANK", "0")) if a.pg == "nccl" else 0
+    pf = ShardedLocFilter(a.n, seed=a.seed, device=dev, backend_factory=factory, stage_slack=1.0)
+    pf.set_force_branch(a.force)
+    branches, moved = [], []
+
+    def tap(f):
+        branches.append(-1 if f.last_branch is None else int(f.last_branch))
+        moved.append(f.exchanged_particles)
+    poses = drive(pf, events(a.steps), tap)
+    w, x, y, z, th = pf.download_local()
+    np.savez(os.path.join(a.out, f"rank{rank}.npz"), w=w, x=x, y=y, z=z, th=th, poses=poses,
+             branches=np.array(branches), moved=np.array(moved), T=np.array(pf.T))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
