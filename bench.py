@@ -9,7 +9,7 @@ depositRange/Rssi call: VIO commit, gate, sums, decision, resample-or-normalise)
 step carries the VIO motion, the second has zero motion.  Particles live in HBM the whole time; the only
 host->device traffic in the timed region is kernel arguments.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--n PARTICLES_PER_GPU] [--force-branch -1|0|1]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--particles PER_GPU] [--force-branch -1|0|1]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): ONE filter of N x 16 M particles sharded by
 particle range; per deposit an all-gather of the per-GPU weight/pose sums (RCCL) gives every rank the
@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=16000000, help="particles per GPU")
+    ap.add_argument("--particles", dest="n", type=int, default=16000000, help="particles per GPU")
     ap.add_argument("--force-branch", type=int, default=-1, help="-1 reference test, 0 never resample, 1 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -124,9 +124,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # BENCH_PG=gloo is a rehearsal mode for a one-GPU box: the ranks share the visible GPUs and the collectives are
+    # staged through the host.  The driver's runs use the default (nccl = RCCL, one GPU per rank).
+    pg = os.environ.get("BENCH_PG", "nccl")
+    if pg != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if pg == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(pg)
 
     from slam3d_amd import particlefilter as pfm
     K, W, n = args.steps, args.warmup, args.n
@@ -166,7 +174,7 @@ def main():
     err = float(np.linalg.norm(np.array(pose[2:5], dtype=np.float64) - truth[W + K - 1]))
 
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if pg == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -175,7 +183,7 @@ def main():
         per = {}
         for nm in ("stream", "stream_static", "resample"):
             sel = ms[kinds == names.index(nm)]
-            if nm == "resample":
+            if nm == "resample" and world == 1:
                 # a resample launch on a normalise-only step exits at once; count only the real ones,
                 # identified by the device-side branch log (one decision per launch, same order)
                 dec = branches[-sel.shape[0]:] if sel.shape[0] else branches[:0]
@@ -188,7 +196,7 @@ def main():
         dominant = max(per, key=lambda k_: per[k_]["total_ms"]) if per else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if dominant and os.path.exists(tpath):
+        if dominant and os.path.exists(tpath) and world == 1 and n == 16000000:
             with open(tpath) as fh:
                 traffic = json.load(fh).get(dominant, {}).get("hbm_bytes_per_launch")
         roof = None
