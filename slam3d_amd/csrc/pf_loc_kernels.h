@@ -193,19 +193,7 @@ __global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(const double* __rest
 }
 
 // ------------------------------------------------------------------ decision (one workgroup)
-constexpr int kDecideThreads = 1024;
-
-__device__ __forceinline__ double block1024_sum(double v, double* lds16)
-{
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) lds16[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += lds16[k];
-    return t;       // every thread gets the same total
-}
+constexpr int kDecideThreads = 64;
 
 // The scalar part of pfResample.c:51-68,80 on the global totals tot[7] = {S, SS, C, SN, WX, WY, WZ} of n
 // particles: ESS / respawn test, heading bandwidth, rStart, or the deferred normalisation factor.
@@ -250,80 +238,61 @@ __device__ __forceinline__ bool decide_scalars(LocCtl* __restrict__ ctl, const d
     return resample;
 }
 
+// One wavefront, no LDS, no barrier: lane l owns the chunks [l*per, (l+1)*per) (per = 1 up to 16.7 M particles).
+// chunkBase is built to be non-decreasing by construction: lane bases by a SEQUENTIAL prefix over the 64 lane
+// totals, values inside a lane by sequential adds capped at the next lane's base.
 template <bool LOCAL_ONLY>
-__global__ __launch_bounds__(kDecideThreads) void k_loc_decide(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
-                                                              double* __restrict__ chunkBase, int numChunks, long long n,
-                                                              float range, RngKey key, int force,
-                                                              unsigned char* __restrict__ branchLog)
+__global__ __launch_bounds__(64) void k_loc_decide(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
+                                                  double* __restrict__ chunkBase, int numChunks, long long n,
+                                                  float range, RngKey key, int force,
+                                                  unsigned char* __restrict__ branchLog)
 {
-    __shared__ double lds16[16];
-    __shared__ double shS;
+    const int lane = threadIdx.x;
+    const int per = (numChunks + 63) / 64;
+    const int begin = min(lane * per, numChunks), end = min(begin + per, numChunks);
 
-    // one chunk per thread (numChunks <= 1024, i.e. n <= 2^28 particles per filter)
-    const int tid = threadIdx.x;
     double loc[7] = { 0, 0, 0, 0, 0, 0, 0 };
-    if (tid < numChunks) {
-        const double* p = chunkSums + (size_t)tid * kSumsPerTile;
+    for (int c = begin; c < end; ++c) {
+        const double* p = chunkSums + (size_t)c * kSumsPerTile;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) loc[k] = p[k];
+        for (int k = 0; k < 7; ++k) loc[k] += p[k];
     }
-    // exclusive prefix of the chunk weights: wave scan + the 16 wave totals
-    double inc = loc[0];
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double up = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += up;
+    // sequential prefix over the lane totals (every lane computes the same 65 values)
+    double laneBase = 0.0, nextBase = 0.0, run = 0.0;
+    for (int l = 0; l < 64; ++l) {
+        const double t = __shfl(loc[0], l, 64);
+        if (l == lane) laneBase = run;
+        run += t;
+        if (l == lane) nextBase = run;
     }
-    if (lane == 63) lds16[wave] = inc;
-    __syncthreads();
-    double pre = 0.0;
-    for (int k = 0; k < wave; ++k) pre += lds16[k];
-    const double exclInWave = __shfl_up(inc, 1, 64);
-    double start = pre + (lane == 0 ? 0.0 : exclInWave);
-    // make the chunk bases non-decreasing whatever the rounding of the parallel scan did (max-scan)
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double up = __shfl_up(start, off, 64);
-        if (lane >= off) start = up > start ? up : start;
+    const double S = run;
+    double v = laneBase;
+    for (int c = begin; c < end; ++c) {
+        chunkBase[c] = v < nextBase ? v : nextBase;
+        v += chunkSums[(size_t)c * kSumsPerTile];
     }
-    __syncthreads();
-    if (lane == 63) lds16[wave] = start;
-    __syncthreads();
-    for (int k = 0; k < wave; ++k) start = lds16[k] > start ? lds16[k] : start;
-    if (tid < numChunks) chunkBase[tid] = start;
-    if (tid == numChunks - 1) {
-        const double S = start + loc[0];
-        chunkBase[numChunks] = S;
-        shS = S;
-    }
+    if (lane == 0) chunkBase[numChunks] = S;
 
     double tot[7];
-    tot[0] = 0.0;
+    tot[0] = S;
 #pragma unroll
-    for (int k = 1; k < 7; ++k) tot[k] = block1024_sum(loc[k], lds16);
-    __syncthreads();
+    for (int k = 1; k < 7; ++k) tot[k] = wave_sum(loc[k]);
 
+    if (lane != 0) return;
     if (LOCAL_ONLY) {
         // sharded filter: publish the local sums; the decision is taken after the all-gather
-        if (tid == 0) {
-            ctl->local[0] = shS;
 #pragma unroll
-            for (int k = 1; k < 7; ++k) ctl->local[k] = tot[k];
-            ctl->local[7] = 0.0;
-        }
+        for (int k = 0; k < 7; ++k) ctl->local[k] = tot[k];
+        ctl->local[7] = 0.0;
         return;
     }
-    if (tid == 0) {
-        tot[0] = shS;
-        const bool resample = decide_scalars(ctl, tot, n, range, key, force, branchLog);
-        if (!resample) {    // the streaming pass's sums are the pose sums of the (unnormalised) current particles
-            ctl->pose[0] = tot[0]; ctl->pose[1] = tot[4]; ctl->pose[2] = tot[5]; ctl->pose[3] = tot[6];
-            ctl->pose[4] = tot[2]; ctl->pose[5] = tot[3];
-        }
-        ctl->shardBase = 0.0; ctl->shardEnd = tot[0];
-        ctl->outBegin = 0; ctl->outEnd = n; ctl->selfBegin = 0; ctl->selfEnd = n; ctl->nGlobal = n;
+    const bool resample = decide_scalars(ctl, tot, n, range, key, force, branchLog);
+    if (!resample) {    // the streaming pass's sums are the pose sums of the (unnormalised) current particles
+        ctl->pose[0] = tot[0]; ctl->pose[1] = tot[4]; ctl->pose[2] = tot[5]; ctl->pose[3] = tot[6];
+        ctl->pose[4] = tot[2]; ctl->pose[5] = tot[3];
     }
+    ctl->shardBase = 0.0; ctl->shardEnd = tot[0];
+    ctl->outBegin = 0; ctl->outEnd = n; ctl->selfBegin = 0; ctl->selfEnd = n; ctl->nGlobal = n;
 }
 
 // Sharded filter, after the all-gather of every shard's local sums (all[g*8 + k], g in rank order): the same
