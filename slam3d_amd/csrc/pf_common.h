@@ -64,13 +64,55 @@ __host__ __device__ __forceinline__ float uniform01(uint32_t word) { return (flo
 // pfRandom.c:100-103 -- (r + 1) / 2^31 in (0,1]
 __host__ __device__ __forceinline__ float uniform_nonzero(uint32_t word) { return (float)(r31(word) + 1u) * kInv2p31; }
 
-// pfRandom.c:67-74 -- Box-Muller pair from two words (u1 first)
+// ---------------------------------------------------------------- float transcendentals, sized for this path
+// The streaming and resampling kernels are bound by vector-ALU issue, not by HBM, as long as they call the
+// general-purpose library routines (measured: 355 VALU instructions per particle in k_loc_stream, ~100 % VALU
+// busy).  Every angle on this path is bounded (headings |theta| < 4 pi, Box-Muller angles in (0, 2 pi]), every
+// logarithm argument lies in [2^-31, 1], so the routines below drop the large-argument, denormal and NaN paths.
+
+// sin and cos of x, |x| <~ 100: three-step Cody-Waite reduction by pi/2 (fused multiply-adds on purpose: the
+// reduction needs the exact product), then polynomials on [-pi/4, pi/4] (own least-squares fit,
+// tools/fit_sincos.py).  Max error 7.1e-8 absolute against float64 over |x| <= 13; differs from glibc's
+// sinf/cosf by at most 1 ulp (5.96e-8) on 4 % of arguments.
+__device__ __forceinline__ void sincos_bounded(float x, float& s, float& c)
+{
+    const float k = __builtin_rintf(x * 0.636619747f);              // nearest multiple of pi/2
+    float r = __builtin_fmaf(k, -1.57079625129699707031e+00f, x);   // pi/2 = hi + mid + lo
+    r = __builtin_fmaf(k, -7.54978941586159635335e-08f, r);
+    r = __builtin_fmaf(k, -5.39030285815811905290e-15f, r);
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, -1.9502914801705629e-04f, 8.332069963216782e-03f);
+    ps = __builtin_fmaf(z, ps, -1.6666653752326965e-01f);
+    ps = __builtin_fmaf(r, z * ps, r);
+    float pc = __builtin_fmaf(z, 2.4421184207312763e-05f, -1.388721400871873e-03f);
+    pc = __builtin_fmaf(z, pc, 4.166664183139801e-02f);
+    pc = __builtin_fmaf(z, pc, -0.5f);
+    pc = __builtin_fmaf(z, pc, 1.0f);
+    const uint32_t q = (uint32_t)(int)k;
+    const bool odd = (q & 1u) != 0u;
+    const float so = odd ? pc : ps, co = odd ? ps : pc;
+    s = __uint_as_float(__float_as_uint(so) ^ ((q & 2u) << 30));
+    c = __uint_as_float(__float_as_uint(co) ^ (((q + 1u) & 2u) << 30));
+}
+
+// ln(u) for u in [2^-31, 1]: the hardware log2 (1 ulp) times ln 2 carried in two floats
+__device__ __forceinline__ float log_unit(float u)
+{
+    const float y = __builtin_amdgcn_logf(u);
+    const float h = y * 6.93147182464599609375e-01f;
+    float l = __builtin_fmaf(y, 6.93147182464599609375e-01f, -h);
+    l = __builtin_fmaf(y, -1.90465429995776804525e-09f, l);
+    return h + l;
+}
+
+// pfRandom.c:67-74 -- Box-Muller pair from two words (u1 first).  The square root is the hardware's
+// (1 ulp, not correctly rounded): the result only ever scales a noise term of at most 0.1 m.
 __device__ __forceinline__ void normal2(uint32_t w0, uint32_t w1, float& a, float& b)
 {
-    const float f = sqrtf(-2.0f * logf(uniform_nonzero(w0)));
+    const float f = __builtin_amdgcn_sqrtf(-2.0f * log_unit(uniform_nonzero(w0)));
     const float g = uniform_nonzero(w1) * 2.0f * kPi;
     float sn, cs;
-    sincosf(g, &sn, &cs);
+    sincos_bounded(g, sn, cs);
     a = f * cs;
     b = f * sn;
 }
@@ -111,8 +153,8 @@ __device__ __forceinline__ void spawn_from_range(const RngKey& key, uint64_t ind
     const float elev = asinf(uniform01(next()) * 2.0f - 1.0f);
     const float azim = uniform01(next()) * 2.0f * kPi;
     float se, ce, sa, ca;
-    sincosf(elev, &se, &ce);
-    sincosf(azim, &sa, &ca);
+    sincos_bounded(elev, se, ce);
+    sincos_bounded(azim, sa, ca);
     const float c = rad * ce;
     x = cx + c * ca;
     y = cy + c * sa;
@@ -206,6 +248,16 @@ __device__ __forceinline__ int upper_bound_clamped(const T* cdf, int n, T u)
         if (u < cdf[mid]) hi = mid; else lo = mid + 1;
     }
     return lo;
+}
+
+// The same selection over a table of exactly kTile entries in LDS whose entries from n on hold +inf:
+// ten unrolled, branch-free halving steps (first j with u < cdf[j], clamped to n-1; NaNs end at n-1 as above).
+__device__ __forceinline__ int upper_bound_tile(const double* cdf, int n, double u)
+{
+    int pos = 0;
+#pragma unroll
+    for (int step = kTile / 2; step >= 1; step >>= 1) pos += (u < cdf[pos + step - 1]) ? 0 : step;
+    return pos < n ? pos : n - 1;
 }
 
 }  // namespace pf

@@ -148,9 +148,9 @@ int check_launch(const char* what)
     return 0;
 }
 
-int launch_set_ctl(pfx_loc* pf, int cur, int branch, float wscale, int keepCur)
+int launch_set_ctl(pfx_loc* pf, int cur, int branch, float wscale, int keepCur, int rsValid = 0)
 {
-    hipLaunchKernelGGL(k_loc_set_ctl, dim3(1), dim3(64), 0, pf->stream, pf->ctl, cur, branch, wscale, keepCur);
+    hipLaunchKernelGGL(k_loc_set_ctl, dim3(1), dim3(64), 0, pf->stream, pf->ctl, cur, branch, wscale, keepCur, rsValid);
     return check_launch("k_loc_set_ctl");
 }
 
@@ -192,20 +192,31 @@ int launch_resample(pfx_loc* pf, float bx, float by, float bz, float range, floa
     for (int k = 0; k < 4; ++k) st.a[k] = pf->stageSlab ? pf->stageSlab + (size_t)k * pf->stageCap : nullptr;
     if (pf->recordAnc)
         hipLaunchKernelGGL((k_loc_resample<true>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->chunkBase, pf->tileIncl,
-                           pf->rsPart, pf->anc, pf->numTiles, pf->n, st, key_of(pf), bx, by, bz, range, stdRange);
+                           pf->anc, pf->numTiles, pf->n, st, key_of(pf), bx, by, bz, range, stdRange);
     else
         hipLaunchKernelGGL((k_loc_resample<false>), grid, block, 0, pf->stream, pf->bufs, pf->ctl, pf->chunkBase, pf->tileIncl,
-                           pf->rsPart, (int*)nullptr, pf->numTiles, pf->n, st, key_of(pf), bx, by, bz, range, stdRange);
+                           (int*)nullptr, pf->numTiles, pf->n, st, key_of(pf), bx, by, bz, range, stdRange);
     return check_launch("k_loc_resample");
 }
 
 int launch_spawn(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
 {
-    if (launch_set_ctl(pf, 0, 1, 1.0f, 0)) return -1;
+    if (launch_set_ctl(pf, 0, 1, 1.0f, 0, 1)) return -1;    // the spawn kernel leaves the pose partials in rsPart
     ProfScope ps(pf, PFX_K_SPAWN);
     hipLaunchKernelGGL(k_loc_spawn, dim3(pf->numTiles), dim3(kThreads), 0, pf->stream, pf->bufs, pf->ctl, pf->rsPart, pf->n,
                        pf->selfBegin, key_of(pf), bx, by, bz, range, stdRange);
     return check_launch("k_loc_spawn");
+}
+
+// pose sums of the current particles into ctl->pose: the per-tile partials come from the streaming pass
+// (normalise-only step), from the spawn kernel, or -- after a resampling step -- from k_loc_pose_tiles here
+int launch_pose(pfx_loc* pf)
+{
+    ProfScope ps(pf, PFX_K_POSE);
+    hipLaunchKernelGGL(k_loc_pose_tiles, dim3(pf->numTiles), dim3(kThreads), 0, pf->stream, pf->bufs, pf->ctl, pf->rsPart, pf->n);
+    if (check_launch("k_loc_pose_tiles")) return -1;
+    hipLaunchKernelGGL(k_loc_pose, dim3(1), dim3(kThreads), 0, pf->stream, pf->ctl, pf->tileSums, pf->rsPart, pf->numTiles, pf->n);
+    return check_launch("k_loc_pose");
 }
 
 Motion motion_of(const float d[5])
@@ -412,12 +423,7 @@ extern "C" int pfx_loc_get_tag_loc(pfx_loc* pf, double* t, float* x, float* y, f
     if (!pf->initialized) return 0;
     DeviceGuard g(pf->device);
     if (pf->poseDirty) {
-        {
-            ProfScope ps(pf, PFX_K_POSE);
-            hipLaunchKernelGGL(k_loc_pose, dim3(1), dim3(kThreads), 0, pf->stream, pf->ctl, pf->tileSums, pf->rsPart,
-                               pf->numTiles, pf->n);
-            if (check_launch("k_loc_pose")) return -1;
-        }
+        if (launch_pose(pf)) return -1;
         if (read_ctl(pf)) return -1;
         pf->poseDirty = false;
     }
@@ -699,11 +705,7 @@ extern "C" int pfx_loc_shard_pose_sums(pfx_loc* pf, double out[6])
 {
     clear_error();
     DeviceGuard g(pf->device);
-    {
-        ProfScope ps(pf, PFX_K_POSE);
-        hipLaunchKernelGGL(k_loc_pose, dim3(1), dim3(kThreads), 0, pf->stream, pf->ctl, pf->tileSums, pf->rsPart, pf->numTiles, pf->n);
-        if (check_launch("k_loc_pose")) return -1;
-    }
+    if (launch_pose(pf)) return -1;
     if (read_ctl(pf)) return -1;
     for (int k = 0; k < 6; ++k) out[k] = pf->hostCtl->pose[k];
     return 0;

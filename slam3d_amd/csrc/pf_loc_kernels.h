@@ -34,6 +34,7 @@ struct LocCtl {
     int src, dst;       // chosen by k_loc_decide for k_loc_resample
     int branch;         // 0 normalise-only, 1 resampled (or freshly spawned)
     int numSpawn;
+    int rsValid;        // rsPart holds the pose partials of the current particles (after a spawn or a pose pass)
     float wscale;       // pending factor on the stored weights
     float htheta;
     float s, ss, csum, ssum, ess, m;    // the reference's float totals (diagnostics / pfx_loc_last_stats)
@@ -98,30 +99,47 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
 
     double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
     bool thetaChanged = false;
+    // The heading noise of one deposit is stdTheta * n with |n| < 6.6: as long as that stays below 1e-3 rad the
+    // sine and cosine of the heading BEFORE the noise (pfMeasurement.c:36-37) follow from those after it
+    // (needed for the sums) by the angle-difference formulas to second order (error < 5e-11), which saves
+    // one sincos per particle in a kernel bound by vector-ALU issue.
+    const bool smallTurn = mo.stdTheta <= 1e-4f;
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
         const long long i = base + k;
         float wi = (i < n) ? w[k] * wscale : 0.0f;      // pad lanes never carry weight
         float thi = th[k];
+        float sn, cs;                                   // of the heading after this deposit
         if (MOTION) {
             // pfMeasurement.c:36-47
-            float s0, c0;
-            sincosf(thi, &s0, &c0);
-            const float pDx = mo.dx * c0 - mo.dy * s0;
-            const float pDy = mo.dx * s0 + mo.dy * c0;
             const u32x4 r = rng_block(key, P_VIO, (uint64_t)(idx0 + i), 0);
             float rx, ry, rz, rth;
             normal2(r.a, r.b, rx, ry);
             normal2(r.c, r.d, rz, rth);
+            const float d = mo.stdTheta * rth;
+            float s0, c0;
+            if (smallTurn) {
+                thi = wrap_two_pi(thi + d);
+                sincos_bounded(thi, sn, cs);
+                const float h = 0.5f * d * d;
+                c0 = __builtin_fmaf(d, sn, __builtin_fmaf(-h, cs, cs));     // cos(theta - d)
+                s0 = __builtin_fmaf(-d, cs, __builtin_fmaf(-h, sn, sn));    // sin(theta - d)
+            } else {
+                sincos_bounded(thi, s0, c0);
+                thi = wrap_two_pi(thi + d);
+                sincos_bounded(thi, sn, cs);
+            }
+            const float pDx = mo.dx * c0 - mo.dy * s0;
+            const float pDy = mo.dx * s0 + mo.dy * c0;
             x[k] += pDx + mo.stdXyz * rx;
             y[k] += pDy + mo.stdXyz * ry;
             z[k] += mo.dz + mo.stdXyz * rz;
-            thi = wrap_two_pi(thi + mo.stdTheta * rth);
         } else {
             // zero motion leaves x,y,z untouched and theta = fmodf(theta, 2pi): a no-op unless |theta| >= 2pi
             const float t2 = wrap_two_pi(thi);
             thetaChanged |= (t2 != thi);
             thi = t2;
+            sincos_bounded(thi, sn, cs);
         }
         th[k] = thi;
         if (GATE) {
@@ -132,8 +150,6 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
         }
         w[k] = wi;
         // pfResample.c:44-48 and particleFilter.c:266-272: float products, added in double
-        float sn, cs;
-        sincosf(thi, &sn, &cs);
         acc[0] += wi;
         acc[1] += wi * wi;
         acc[2] += wi * cs;
@@ -226,7 +242,7 @@ __device__ __forceinline__ bool decide_scalars(LocCtl* __restrict__ ctl, const d
         const double rStart = (double)uniform01(rng_block(key, P_RSTART, 0, 0).a) * rStep;
         ctl->htheta = h; ctl->rStep = rStep; ctl->rStart = rStart;
         ctl->src = cur; ctl->dst = cur ^ 1; ctl->cur = cur ^ 1;
-        ctl->wscale = 1.0f; ctl->m = 0.0f; ctl->branch = 1;
+        ctl->wscale = 1.0f; ctl->m = 0.0f; ctl->branch = 1; ctl->rsValid = 0;
     } else {
         // pfResample.c:80-82, deferred: the next reader multiplies w by m
         const float m = (float)n / s;
@@ -375,90 +391,121 @@ template <bool RECORD>
 __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const LocCtl* __restrict__ ctl,
                                                           const double* __restrict__ chunkBase,
                                                           const double* __restrict__ tileIncl,
-                                                          double* __restrict__ rsPart, int* __restrict__ ancOut,
+                                                          int* __restrict__ ancOut,
                                                           int numTiles, long long n, StagePtrs stage, RngKey key,
                                                           float bx, float by, float bz, float range, float stdRange)
 {
     if (ctl->branch != 1) return;           // normalise-only step: nothing to do (wave-uniform exit)
 
     __shared__ double cdf[kTile];
-    __shared__ double red[4 * 6];
+    __shared__ double red[4];
+    __shared__ long long span[2];
     const int t = blockIdx.x, tid = threadIdx.x;
     const double rStart = ctl->rStart, rStep = ctl->rStep;
     const double shardBase = ctl->shardBase, shardEnd = ctl->shardEnd;
-    const long long nGlobal = ctl->nGlobal;
-    // Offspring range of this tile.  Neighbouring workgroups (and neighbouring shards) evaluate the same
-    // expression for a shared boundary, so the ranges tile [outBegin, outEnd) exactly.
     const double tileStart = tile_start_cdf(chunkBase, tileIncl, t, shardBase, shardEnd);
-    const long long i0 = (t == 0) ? ctl->outBegin : first_offspring_at(tileStart, rStart, rStep, nGlobal);
-    const long long i1 = (t == numTiles - 1)
-                             ? ctl->outEnd
-                             : first_offspring_at(tile_start_cdf(chunkBase, tileIncl, t + 1, shardBase, shardEnd), rStart, rStep, nGlobal);
-    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    // Offspring range [i0, i1) of this tile.  Neighbouring workgroups (and neighbouring shards) evaluate the
+    // same expression for a shared boundary, so the ranges tile [outBegin, outEnd) exactly.  One lane each of
+    // two different waves does the float64 division; everybody else picks the result up after the barrier.
+    if (tid == 0) {
+        span[0] = (t == 0) ? ctl->outBegin : first_offspring_at(tileStart, rStart, rStep, ctl->nGlobal);
+    } else if (tid == 64) {
+        span[1] = (t == numTiles - 1)
+                      ? ctl->outEnd
+                      : first_offspring_at(tile_start_cdf(chunkBase, tileIncl, t + 1, shardBase, shardEnd), rStart, rStep,
+                                           ctl->nGlobal);
+    }
 
-    if (i0 < i1) {
-        const int src = ctl->src, dst = ctl->dst;
-        const float* __restrict__ sw = bufs.a[src][0];
-        const float* __restrict__ sx = bufs.a[src][1];
-        const float* __restrict__ sy = bufs.a[src][2];
-        const float* __restrict__ sz = bufs.a[src][3];
-        const float* __restrict__ st = bufs.a[src][4];
-        float* __restrict__ dw = bufs.a[dst][0];
-        float* __restrict__ dx = bufs.a[dst][1];
-        float* __restrict__ dy = bufs.a[dst][2];
-        float* __restrict__ dz = bufs.a[dst][3];
-        float* __restrict__ dt = bufs.a[dst][4];
+    // this tile's CDF, rebuilt from the weights (pfResample.c:45,49 in double): tile start + inclusive scan
+    const int src = ctl->src, dst = ctl->dst;
+    const long long tbase = (long long)t * kTile;
+    const float4 w4 = *reinterpret_cast<const float4*>(bufs.a[src][0] + tbase + tid * kPerThread);
+    const double a0 = w4.x, a1 = a0 + w4.y, a2 = a1 + w4.z, a3 = a2 + w4.w;
+    double total;
+    const double incl = block_inclusive_scan(a3, red, total);
+    const double off = tileStart + (incl - a3);
+    const long long rem = n - tbase;
+    const int nValid = rem < kTile ? (int)rem : kTile;
+    const double inf = __builtin_huge_val();            // pad entries of the last tile: never selected
+    cdf[tid * 4 + 0] = (tid * 4 + 0 < nValid) ? off + a0 : inf;
+    cdf[tid * 4 + 1] = (tid * 4 + 1 < nValid) ? off + a1 : inf;
+    cdf[tid * 4 + 2] = (tid * 4 + 2 < nValid) ? off + a2 : inf;
+    cdf[tid * 4 + 3] = (tid * 4 + 3 < nValid) ? off + a3 : inf;
+    __syncthreads();
+    const long long i0 = span[0], i1 = span[1];
+    if (i0 >= i1) return;
 
-        // this tile's CDF, rebuilt from the weights (pfResample.c:45,49 in double): tile start + inclusive scan
-        const long long tbase = (long long)t * kTile;
-        const float4 w4 = *reinterpret_cast<const float4*>(sw + tbase + tid * kPerThread);
-        const double a0 = w4.x, a1 = a0 + w4.y, a2 = a1 + w4.z, a3 = a2 + w4.w;
-        double total;
-        const double incl = block_inclusive_scan(a3, red, total);
-        const double off = tileStart + (incl - a3);
-        cdf[tid * 4 + 0] = off + a0;
-        cdf[tid * 4 + 1] = off + a1;
-        cdf[tid * 4 + 2] = off + a2;
-        cdf[tid * 4 + 3] = off + a3;
-        __syncthreads();
+    const float* __restrict__ sx = bufs.a[src][1];
+    const float* __restrict__ sy = bufs.a[src][2];
+    const float* __restrict__ sz = bufs.a[src][3];
+    const float* __restrict__ st = bufs.a[src][4];
+    float* __restrict__ dw = bufs.a[dst][0];
+    float* __restrict__ dx = bufs.a[dst][1];
+    float* __restrict__ dy = bufs.a[dst][2];
+    float* __restrict__ dz = bufs.a[dst][3];
+    float* __restrict__ dt = bufs.a[dst][4];
 
-        const long long rem = n - tbase;
-        const int nValid = rem < kTile ? (int)rem : kTile;
-        const float hTheta = ctl->htheta;
-        const int numSpawn = ctl->numSpawn;
-        const long long selfBegin = ctl->selfBegin, selfEnd = ctl->selfEnd, outBegin = ctl->outBegin;
-        const long long outEnd = ctl->outEnd;
-        // staged offspring: those below the shard's own range first, then those above it
-        const long long below = selfBegin > outBegin ? (selfBegin < outEnd ? selfBegin : outEnd) - outBegin : 0;
-        const long long aboveStart = selfEnd > outBegin ? selfEnd : outBegin;
+    const float hTheta = ctl->htheta;
+    const int numSpawn = ctl->numSpawn;
+    const long long selfBegin = ctl->selfBegin, selfEnd = ctl->selfEnd, outBegin = ctl->outBegin;
+    const long long outEnd = ctl->outEnd;
+    // staged offspring: those below the shard's own range first, then those above it
+    const long long below = selfBegin > outBegin ? (selfBegin < outEnd ? selfBegin : outEnd) - outBegin : 0;
+    const long long aboveStart = selfEnd > outBegin ? selfEnd : outBegin;
 
-        for (long long i = i0 + tid; i < i1; i += kThreads) {
-            const double u = rStart + rStep * (double)i;        // pfResample.c:71
-            const int j = upper_bound_clamped<double>(cdf, nValid, u);
-            const long long a = tbase + j;
-            float x, y, z, th;
-            if (i < numSpawn) {
-                spawn_from_range(key, (uint64_t)i, bx, by, bz, range, stdRange, x, y, z, th);   // pfResample.c:75-76
-            } else {
-                spawn_from_other(key, (uint64_t)i, sx[a], sy[a], sz[a], st[a], kHxyz, hTheta, x, y, z, th);
-            }
-            if (i >= selfBegin && i < selfEnd) {
-                const long long p = i - selfBegin;
-                dw[p] = 1.0f; dx[p] = x; dy[p] = y; dz[p] = z; dt[p] = th;
-                if (RECORD) ancOut[p] = (int)a;
-            } else {
-                const long long p = (i < selfBegin) ? i - outBegin : (i - aboveStart) + below;
-                stage.a[0][p] = x; stage.a[1][p] = y; stage.a[2][p] = z; stage.a[3][p] = th;
-            }
-            float sn, cs;
-            sincosf(th, &sn, &cs);
-            acc[0] += x; acc[1] += y; acc[2] += z; acc[3] += cs; acc[4] += sn; acc[5] += 1.0;
+    for (long long i = i0 + tid; i < i1; i += kThreads) {
+        const double u = rStart + rStep * (double)i;        // pfResample.c:71
+        const int j = upper_bound_tile(cdf, nValid, u);
+        const long long a = tbase + j;
+        float x, y, z, th;
+        if (i < numSpawn) {
+            spawn_from_range(key, (uint64_t)i, bx, by, bz, range, stdRange, x, y, z, th);   // pfResample.c:75-76
+        } else {
+            spawn_from_other(key, (uint64_t)i, sx[a], sy[a], sz[a], st[a], kHxyz, hTheta, x, y, z, th);
         }
-        __syncthreads();
+        if (i >= selfBegin && i < selfEnd) {
+            const long long p = i - selfBegin;
+            dw[p] = 1.0f; dx[p] = x; dy[p] = y; dz[p] = z; dt[p] = th;
+            if (RECORD) ancOut[p] = (int)a;
+        } else {
+            const long long p = (i < selfBegin) ? i - outBegin : (i - aboveStart) + below;
+            stage.a[0][p] = x; stage.a[1][p] = y; stage.a[2][p] = z; stage.a[3][p] = th;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pose sums after a resampling step
+// The resample kernel does not accumulate the pose sums of the offspring (a sincos per particle in a kernel bound
+// by vector-ALU issue, for a result most deposits never ask for).  When a pose is asked for after a resampling
+// step, this pass computes the per-tile sums of w, wx, wy, wz, w cos, w sin over the current particles
+// (particleFilter.c:263-273); after a normalise-only step, or when the partials are already there, it exits.
+__global__ __launch_bounds__(kThreads) void k_loc_pose_tiles(LocBufs bufs, const LocCtl* __restrict__ ctl,
+                                                            double* __restrict__ rsPart, long long n)
+{
+    if (ctl->branch != 1 || ctl->rsValid) return;
+    __shared__ double red[4 * 6];
+    const int cur = ctl->cur;
+    const float wscale = ctl->wscale;
+    const long long base = (long long)blockIdx.x * kTile + (long long)threadIdx.x * kPerThread;
+    const float4 w4 = *reinterpret_cast<const float4*>(bufs.a[cur][0] + base);
+    const float4 x4 = *reinterpret_cast<const float4*>(bufs.a[cur][1] + base);
+    const float4 y4 = *reinterpret_cast<const float4*>(bufs.a[cur][2] + base);
+    const float4 z4 = *reinterpret_cast<const float4*>(bufs.a[cur][3] + base);
+    const float4 t4 = *reinterpret_cast<const float4*>(bufs.a[cur][4] + base);
+    const float w[4] = { w4.x, w4.y, w4.z, w4.w }, x[4] = { x4.x, x4.y, x4.z, x4.w }, y[4] = { y4.x, y4.y, y4.z, y4.w };
+    const float z[4] = { z4.x, z4.y, z4.z, z4.w }, th[4] = { t4.x, t4.y, t4.z, t4.w };
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        const float wi = (base + k < n) ? w[k] * wscale : 0.0f;
+        float sn, cs;
+        sincos_bounded(th[k], sn, cs);
+        acc[0] += wi * x[k]; acc[1] += wi * y[k]; acc[2] += wi * z[k];
+        acc[3] += wi * cs; acc[4] += wi * sn; acc[5] += wi;
     }
     block_sum<6>(acc, red);
-    if (tid == 0) {
-        double* o = rsPart + (size_t)t * kRsPerTile;
+    if (threadIdx.x == 0) {
+        double* o = rsPart + (size_t)blockIdx.x * kRsPerTile;
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[k] = acc[k];
     }
@@ -486,7 +533,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_spawn(LocBufs bufs, LocCtl* __
             spawn_from_range(key, (uint64_t)(idx0 + i), bx, by, bz, range, stdRange, x, y, z, th);
             pw[i] = 1.0f; px[i] = x; py[i] = y; pz[i] = z; pt[i] = th;
             float sn, cs;
-            sincosf(th, &sn, &cs);
+            sincos_bounded(th, sn, cs);
             acc[0] += x; acc[1] += y; acc[2] += z; acc[3] += cs; acc[4] += sn; acc[5] += 1.0;
         } else {
             pw[i] = 0.0f; px[i] = 0.0f; py[i] = 0.0f; pz[i] = 0.0f; pt[i] = 0.0f;
@@ -501,12 +548,13 @@ __global__ __launch_bounds__(kThreads) void k_loc_spawn(LocBufs bufs, LocCtl* __
 }
 
 // ------------------------------------------------------------------ small control kernels
-__global__ void k_loc_set_ctl(LocCtl* ctl, int cur, int branch, float wscale, int keepCur)
+__global__ void k_loc_set_ctl(LocCtl* ctl, int cur, int branch, float wscale, int keepCur, int rsValid)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (!keepCur) ctl->cur = cur;
         ctl->branch = branch;
         ctl->wscale = wscale;
+        ctl->rsValid = rsValid;
     }
 }
 
@@ -531,6 +579,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_pose(LocCtl* __restrict__ ctl,
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) ctl->pose[k] = acc[k];
+        if (branch == 1) ctl->rsValid = 1;
     }
 }
 
