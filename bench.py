@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--particles", dest="n", type=int, default=16000000, help="particles per GPU")
     ap.add_argument("--force-branch", type=int, default=-1, help="-1 reference test, 0 never resample, 1 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="timed region without per-kernel HIP events (no roofline)")
     args = ap.parse_args()
 
     import torch
@@ -159,7 +160,8 @@ def main():
         step(pf, k, bx, truth, rng)
     barrier()
 
-    pf.profile_begin(4 * K * 3 + 16)
+    if not args.no_kernel_events:
+        pf.profile_begin(4 * K * 3 + 16)
     barrier()
     t0 = time.perf_counter()
     for k in range(W, W + K):
