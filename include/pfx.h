@@ -124,6 +124,52 @@ int      pfx_loc_shard_pose_sums(pfx_loc* pf, double out[6]);   /* local sums of
 /* particleFilter.c:274-290 on caller-supplied (e.g. all-reduced) pose sums; 1 ok, 0 not initialised */
 int      pfx_loc_pose_from_sums(pfx_loc* pf, const double sums[6], double* t, float* x, float* y, float* z, float* theta);
 
+/* ---- particleFilterSlam with runtime sizes, batched (BASELINE.json configs[4]) ----
+ * A pfx_slam is a batch of `num_filters` independent SLAM filters on one GPU: each has n_tag tag particles
+ * (reference: PF_N_TAG_SLAM = 100, particleFilter.h:19) and up to max_bcns (<= 32) beacons of n_tag x n_bcn
+ * particles (PF_N_BCN = 1000, :20); n_tag, n_bcn <= 1024.  Filter f draws its noise from Philox key
+ * (seeds[f], or seed0 + f when seeds is NULL); beacon slot c uses sub-stream c + 1, the tag particles 0.
+ * The per-filter calls mirror particleFilterSlam_* one to one (particleFilter.c:48-68, 106-176, 193-246,
+ * 293-387; `allBcns` = every beacon added to the filter); the *_batch calls do the same for every filter
+ * of the batch in one set of kernel launches. */
+typedef struct pfx_slam pfx_slam;
+pfx_slam* pfx_slam_create(int num_filters, int n_tag, int n_bcn, int max_bcns, const uint32_t* seeds, uint32_t seed0, int device);
+void     pfx_slam_destroy(pfx_slam* pf);
+int      pfx_slam_num_filters(const pfx_slam* pf);
+int      pfx_slam_n_tag(const pfx_slam* pf);
+int      pfx_slam_n_bcn(const pfx_slam* pf);
+int      pfx_slam_max_bcns(const pfx_slam* pf);
+int      pfx_slam_sync(pfx_slam* pf);
+int      pfx_slam_reset(pfx_slam* pf, int f, uint32_t seed);                    /* particleFilterSlam_init of filter f */
+int      pfx_slam_add_bcn(pfx_slam* pf, int f);                                 /* particleFilterSlam_addBcn; returns the slot */
+int      pfx_slam_bcn_initialized(const pfx_slam* pf, int f, int slot);
+uint32_t pfx_slam_epoch(const pfx_slam* pf, int f);                             /* Philox counter word 2: one per deposit */
+void     pfx_slam_set_epoch(pfx_slam* pf, int f, uint32_t epoch);
+uint32_t pfx_slam_seed(const pfx_slam* pf, int f);
+int      pfx_slam_deposit_tag_vio(pfx_slam* pf, int f, double t, float x, float y, float z, float dist);
+int      pfx_slam_deposit_bcn_vio(pfx_slam* pf, int f, int slot, double t, float x, float y, float z, float dist);
+int      pfx_slam_deposit_range(pfx_slam* pf, int f, int slot, float range, float stdRange);
+int      pfx_slam_deposit_rssi(pfx_slam* pf, int f, int slot, int rssi);
+int      pfx_slam_get_tag_loc(pfx_slam* pf, int f, double* t, float* x, float* y, float* z, float* theta);          /* 1 ok, <0 error */
+int      pfx_slam_get_bcn_loc(pfx_slam* pf, int f, int slot, double* t, float* x, float* y, float* z, float* theta); /* 1 ok, 0 beacon not initialised */
+int      pfx_slam_last_tag_branch(pfx_slam* pf, int f);     /* 1: the last deposit resampled the tag particles (pfResample.c:110) */
+/* whole batch: arrays of num_filters entries; slot[f] < 0 = no measurement for filter f in this deposit */
+int      pfx_slam_deposit_tag_vio_batch(pfx_slam* pf, const double* t, const float* x, const float* y, const float* z, const float* dist);
+int      pfx_slam_deposit_range_batch(pfx_slam* pf, const int32_t* slot, const float* range, const float* stdRange);
+int      pfx_slam_get_tag_loc_batch(pfx_slam* pf, double* t, float* x, float* y, float* z, float* theta);
+int      pfx_slam_get_bcn_loc_batch(pfx_slam* pf, const int32_t* slot, uint8_t* ok, double* t, float* x, float* y, float* z, float* theta);
+/* state: tag arrays of n_tag floats; beacon arrays of n_tag * n_bcn floats, row i = pBcn[i][*] (particleFilter.h:86) */
+int      pfx_slam_download_tag(pfx_slam* pf, int f, float* w, float* x, float* y, float* z, float* theta);
+int      pfx_slam_upload_tag(pfx_slam* pf, int f, const float* w, const float* x, const float* y, const float* z, const float* theta);
+int      pfx_slam_download_bcn(pfx_slam* pf, int f, int slot, float* w, float* x, float* y, float* z, float* theta);
+int      pfx_slam_upload_bcn(pfx_slam* pf, int f, int slot, const float* w, const float* x, const float* y, const float* z,
+                             const float* theta, int initialized);
+/* binding between the reference-layout structs and device filters */
+pfx_slam* pfx_slam_of(const particleFilterSlam_t* pf);                       /* NULL if the struct is not bound */
+int      pfx_slam_slot_of(const particleFilterSlam_t* pf, const bcn_t* bcn); /* -1 until the beacon's first deposit */
+int      pfx_slam_sync_host(particleFilterSlam_t* pf, bcn_t* bcn);           /* fill pTag[] and (bcn != NULL) pBcn[][] from HBM */
+void     pfx_slam_release(particleFilterSlam_t* pf);                         /* free the device side */
+
 /* ---- binding between the reference-layout structs and device filters ---- */
 pfx_loc* pfx_loc_of(const particleFilterLoc_t* pf);          /* NULL if the struct is not bound */
 int      pfx_loc_sync_host(particleFilterLoc_t* pf);         /* fill pf->pTag[] (AoS) from HBM */

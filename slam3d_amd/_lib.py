@@ -91,6 +91,48 @@ def lib() -> C.CDLL:
     sig("particleFilterLoc_depositRange", None, vp, f, f, f, f, f)
     sig("particleFilterLoc_depositRssi", None, vp, f, f, f, i)
     sig("particleFilterLoc_getTagLoc", C.c_uint8, vp, pd_, pf_, pf_, pf_, pf_)
+    # batched SLAM filters (pfx_slam_*)
+    u8p = C.POINTER(C.c_uint8)
+    sig("pfx_slam_create", vp, i, i, i, i, vp, u32, i)
+    sig("pfx_slam_destroy", None, vp)
+    sig("pfx_slam_num_filters", i, vp)
+    sig("pfx_slam_n_tag", i, vp)
+    sig("pfx_slam_n_bcn", i, vp)
+    sig("pfx_slam_max_bcns", i, vp)
+    sig("pfx_slam_sync", i, vp)
+    sig("pfx_slam_reset", i, vp, i, u32)
+    sig("pfx_slam_add_bcn", i, vp, i)
+    sig("pfx_slam_bcn_initialized", i, vp, i, i)
+    sig("pfx_slam_epoch", u32, vp, i)
+    sig("pfx_slam_set_epoch", None, vp, i, u32)
+    sig("pfx_slam_seed", u32, vp, i)
+    sig("pfx_slam_deposit_tag_vio", i, vp, i, d, f, f, f, f)
+    sig("pfx_slam_deposit_bcn_vio", i, vp, i, i, d, f, f, f, f)
+    sig("pfx_slam_deposit_range", i, vp, i, i, f, f)
+    sig("pfx_slam_deposit_rssi", i, vp, i, i, i)
+    sig("pfx_slam_get_tag_loc", i, vp, i, pd_, pf_, pf_, pf_, pf_)
+    sig("pfx_slam_get_bcn_loc", i, vp, i, i, pd_, pf_, pf_, pf_, pf_)
+    sig("pfx_slam_last_tag_branch", i, vp, i)
+    sig("pfx_slam_deposit_tag_vio_batch", i, vp, vp, vp, vp, vp, vp)
+    sig("pfx_slam_deposit_range_batch", i, vp, vp, vp, vp)
+    sig("pfx_slam_get_tag_loc_batch", i, vp, vp, vp, vp, vp, vp)
+    sig("pfx_slam_get_bcn_loc_batch", i, vp, vp, vp, vp, vp, vp, vp, vp)
+    sig("pfx_slam_download_tag", i, vp, i, vp, vp, vp, vp, vp)
+    sig("pfx_slam_upload_tag", i, vp, i, vp, vp, vp, vp, vp)
+    sig("pfx_slam_download_bcn", i, vp, i, i, vp, vp, vp, vp, vp)
+    sig("pfx_slam_upload_bcn", i, vp, i, i, vp, vp, vp, vp, vp, i)
+    sig("pfx_slam_of", vp, vp)
+    sig("pfx_slam_slot_of", i, vp, vp)
+    sig("pfx_slam_sync_host", i, vp, vp)
+    sig("pfx_slam_release", None, vp)
+    sig("particleFilterSlam_init", None, vp)
+    sig("particleFilterSlam_addBcn", None, vp)
+    sig("particleFilterSlam_depositTagVio", None, vp, d, f, f, f, f)
+    sig("particleFilterSlam_depositBcnVio", None, vp, d, f, f, f, f)
+    sig("particleFilterSlam_depositRange", None, vp, vp, f, f, vp, i)
+    sig("particleFilterSlam_depositRssi", None, vp, vp, i, vp, i)
+    sig("particleFilterSlam_getTagLoc", C.c_uint8, vp, pd_, pf_, pf_, pf_, pf_)
+    sig("particleFilterSlam_getBcnLoc", C.c_uint8, vp, vp, pd_, pf_, pf_, pf_, pf_)
     _lib = L
     return L
 

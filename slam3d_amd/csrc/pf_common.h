@@ -176,6 +176,41 @@ __device__ __forceinline__ void spawn_from_other(const RngKey& key, uint64_t ind
     theta = wrap_two_pi(oth + dth * hTheta);
 }
 
+// pfMeasurement.c:36-47 (Loc), :61-74 (SLAM tag), :90-104 (SLAM beacon) -- VIO motion of one particle: rotate the
+// delta by the heading, add Gaussian noise, wrap the heading.  Returns sin/cos of the NEW heading (the weight
+// sums need them).  The heading noise is stdTheta * n with |n| < 6.6: while that stays below 1e-3 rad
+// (smallTurn, decided once per launch from stdTheta <= 1e-4) the sine and cosine of the heading BEFORE the noise
+// follow from those after it by the angle-difference formulas to second order (error < 5e-11), which saves one
+// sincos per particle in kernels bound by vector-ALU issue.
+struct Motion { float dx, dy, dz, stdXyz, stdTheta; };
+
+__device__ __forceinline__ void motion_particle(const RngKey& key, uint64_t index, const Motion& mo, bool smallTurn,
+                                                float& x, float& y, float& z, float& th, float& sn, float& cs)
+{
+    const u32x4 r = rng_block(key, P_VIO, index, 0);
+    float rx, ry, rz, rth;
+    normal2(r.a, r.b, rx, ry);
+    normal2(r.c, r.d, rz, rth);
+    const float d = mo.stdTheta * rth;
+    float s0, c0;
+    if (smallTurn) {
+        th = wrap_two_pi(th + d);
+        sincos_bounded(th, sn, cs);
+        const float h = 0.5f * d * d;
+        c0 = __builtin_fmaf(d, sn, __builtin_fmaf(-h, cs, cs));     // cos(theta - d)
+        s0 = __builtin_fmaf(-d, cs, __builtin_fmaf(-h, sn, sn));    // sin(theta - d)
+    } else {
+        sincos_bounded(th, s0, c0);
+        th = wrap_two_pi(th + d);
+        sincos_bounded(th, sn, cs);
+    }
+    const float pDx = mo.dx * c0 - mo.dy * s0;
+    const float pDy = mo.dx * s0 + mo.dy * c0;
+    x += pDx + mo.stdXyz * rx;
+    y += pDy + mo.stdXyz * ry;
+    z += mo.dz + mo.stdXyz * rz;
+}
+
 // ---------------------------------------------------------------- wave / block reductions (wave = 64)
 __device__ __forceinline__ double wave_sum(double v)
 {

@@ -61,7 +61,6 @@ struct ShardPlan {
 
 constexpr int kBranchLogSize = 65536;
 
-struct Motion { float dx, dy, dz, stdXyz, stdTheta; };
 struct Gate { float bx, by, bz, range, thresh, minWeight; };
 
 constexpr int kSumsPerTile = 8;     // s ss c sn wx wy wz (pad)
@@ -99,10 +98,6 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
 
     double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
     bool thetaChanged = false;
-    // The heading noise of one deposit is stdTheta * n with |n| < 6.6: as long as that stays below 1e-3 rad the
-    // sine and cosine of the heading BEFORE the noise (pfMeasurement.c:36-37) follow from those after it
-    // (needed for the sums) by the angle-difference formulas to second order (error < 5e-11), which saves
-    // one sincos per particle in a kernel bound by vector-ALU issue.
     const bool smallTurn = mo.stdTheta <= 1e-4f;
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
@@ -111,29 +106,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
         float thi = th[k];
         float sn, cs;                                   // of the heading after this deposit
         if (MOTION) {
-            // pfMeasurement.c:36-47
-            const u32x4 r = rng_block(key, P_VIO, (uint64_t)(idx0 + i), 0);
-            float rx, ry, rz, rth;
-            normal2(r.a, r.b, rx, ry);
-            normal2(r.c, r.d, rz, rth);
-            const float d = mo.stdTheta * rth;
-            float s0, c0;
-            if (smallTurn) {
-                thi = wrap_two_pi(thi + d);
-                sincos_bounded(thi, sn, cs);
-                const float h = 0.5f * d * d;
-                c0 = __builtin_fmaf(d, sn, __builtin_fmaf(-h, cs, cs));     // cos(theta - d)
-                s0 = __builtin_fmaf(-d, cs, __builtin_fmaf(-h, sn, sn));    // sin(theta - d)
-            } else {
-                sincos_bounded(thi, s0, c0);
-                thi = wrap_two_pi(thi + d);
-                sincos_bounded(thi, sn, cs);
-            }
-            const float pDx = mo.dx * c0 - mo.dy * s0;
-            const float pDy = mo.dx * s0 + mo.dy * c0;
-            x[k] += pDx + mo.stdXyz * rx;
-            y[k] += pDy + mo.stdXyz * ry;
-            z[k] += mo.dz + mo.stdXyz * rz;
+            motion_particle(key, (uint64_t)(idx0 + i), mo, smallTurn, x[k], y[k], z[k], thi, sn, cs);
         } else {
             // zero motion leaves x,y,z untouched and theta = fmodf(theta, 2pi): a no-op unless |theta| >= 2pi
             const float t2 = wrap_two_pi(thi);

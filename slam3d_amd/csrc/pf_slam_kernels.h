@@ -1,0 +1,431 @@
+// pf_slam_kernels.h -- HIP kernels of the particleFilterSlam hot path (gfx950, wave64).
+//
+// The reference's SLAM filter is Rao-Blackwellised (particleFilter.h:66-100): nTag (100) tag particles, and per
+// beacon one ROW of nBcn (1000) beacon particles for every tag particle.  A row is an independent little particle
+// filter (pfResample.c:141-201), so the unit of work here is ONE WORKGROUP PER ROW: 256 threads x 4 particles, the
+// whole row in registers, its CDF and ancestor copies in LDS, resampled in place (no ping-pong buffer).
+// Many SLAM filters ("a batch", BASELINE.json configs[4]) are one grid dimension more; filters never interact.
+//
+// One deposit (particleFilter.c:193-211) is three launches for the whole batch, no host sync:
+//   k_slam_gate   grid (nTag, F): the measured beacon's row i -- beacon VIO motion (pfMeasurement.c:78-106), range
+//                 gate against tag particle i AFTER its own VIO motion (:127-152; the tag motion is recomputed
+//                 from the same Philox counters, not yet stored), row weight sum.                [HBM: 20 B r + 4..20 B w]
+//   k_slam_tag    grid (F): tag VIO motion (:51-76), w_i *= rowsum_i, ESS test, resample or normalise the tag
+//                 particles (pfResample.c:86-139).                                               [tiny]
+//   k_slam_rows   grid (nTag, B, F): every row that has something to do -- VIO motion of the other beacons, the
+//                 first-range spawn (pfInit.c:34-45), and _resampleBcn (pfResample.c:141-201): of every initialised
+//                 beacon, forced, if the tag particles were resampled; else of the measured beacon only.  Rows with
+//                 nothing to do exit before touching memory.                                     [HBM: 20 B r + 20 B w]
+// Noise: Philox sub-streams keyed (seed of the filter, stream = 0 for the tag / slot+1 for a beacon, epoch = deposit
+// count) and indexed by the particle's position in its array, as the oracle's Philox mode (oracle/pf_oracle.c).
+#pragma once
+
+#include "pf_common.h"
+
+namespace pf {
+
+constexpr int kSlamMaxBcns = 32;        // beacon slots per filter (bit masks below)
+
+struct SlamStep {           // one filter's part of a (batched) deposit
+    int mode;               // 0 no measurement, 1 range on an initialised beacon, 2 first range: spawn the beacon
+    int target;             // beacon slot of the measurement
+    uint32_t seed, epoch;
+    uint32_t activeMask;    // beacons handed to the deposit (allBcns[0..numBcns), particleFilter.c:198-199)
+    uint32_t initMask;      // of those, initialised before this deposit
+    uint32_t movingMask;    // of those, with a non-zero VIO delta to commit
+    int tagMoving;
+    Motion tagMo;
+    float range, stdRange, thresh, minWeight;
+};
+
+struct SlamDims { int numFilters, maxBcns, nTag, nBcn, tagStride, rowStride; };
+struct SlamPtrs { float* tag[5]; float* bcn[5]; };      // w x y z theta
+
+__host__ __device__ __forceinline__ size_t slam_row_base(const SlamDims& D, int f, int c, int k)
+{
+    return (((size_t)f * D.maxBcns + c) * D.nTag + k) * (size_t)D.rowStride;
+}
+
+struct Row4 { float w[4], x[4], y[4], z[4], th[4]; };
+
+__device__ __forceinline__ void row_load(const float* const (&a)[5], size_t base, int j0, int n, Row4& r)
+{
+    float4 v[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) v[q] = (j0 < n) ? *reinterpret_cast<const float4*>(a[q] + base + j0) : make_float4(0, 0, 0, 0);
+    r.w[0] = v[0].x; r.w[1] = v[0].y; r.w[2] = v[0].z; r.w[3] = v[0].w;
+    r.x[0] = v[1].x; r.x[1] = v[1].y; r.x[2] = v[1].z; r.x[3] = v[1].w;
+    r.y[0] = v[2].x; r.y[1] = v[2].y; r.y[2] = v[2].z; r.y[3] = v[2].w;
+    r.z[0] = v[3].x; r.z[1] = v[3].y; r.z[2] = v[3].z; r.z[3] = v[3].w;
+    r.th[0] = v[4].x; r.th[1] = v[4].y; r.th[2] = v[4].z; r.th[3] = v[4].w;
+}
+
+__device__ __forceinline__ void row_store1(float* a, size_t base, int j0, int n, const float (&v)[4])
+{
+    // rows are padded to a multiple of four floats, so a whole float4 may be written when j0 < n
+    if (j0 < n) *reinterpret_cast<float4*>(a + base + j0) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// The scalar part of one small filter's resample-or-normalise decision (pfResample.c:107-121 for the tag
+// particles, :165-184 for a beacon row) on the totals S = sum w (f64), SS, C, SN.
+struct SmallDecision { int resample, numSpawn; float htheta, m; double rStart, rStep; };
+
+__device__ __forceinline__ SmallDecision small_decide(double S, double SS, double C, double SN, int n, float range,
+                                                      bool allowSpawn, bool force, const RngKey& key, uint64_t rsIndex)
+{
+    SmallDecision d;
+    const float s = (float)S, ss = (float)SS;
+    float csum = (float)C, ssum = (float)SN;
+    const float ess = s * s / ss;
+    const float invN = 1.0f / (float)n;
+    d.numSpawn = 0;
+    if (allowSpawn && s * invN < kWeightSpawnThresh && range < kRadiusSpawnThresh) d.numSpawn = (int)lroundf((float)n * kPctSpawn);
+    d.resample = ((ess * invN < kResampleThresh) || d.numSpawn > 0 || force) ? 1 : 0;
+    d.htheta = 0.0f; d.m = 0.0f; d.rStart = 0.0; d.rStep = 0.0;
+    if (d.resample) {
+        csum /= s;
+        ssum /= s;
+        float h = csum * csum + ssum * ssum;
+        h = h > 1e-10f ? h : 1e-10f;
+        h = h < 1.0f - 1e-10f ? h : 1.0f - 1e-10f;
+        d.htheta = sqrtf(-logf(h) / ess);
+        d.rStep = S / (double)n;
+        d.rStart = (double)uniform01(rng_block(key, P_RSTART, rsIndex, 0).a) * d.rStep;
+    } else {
+        d.m = (float)n / s;
+    }
+    return d;
+}
+
+// Shared-memory working set of one small filter (a tag particle set or one beacon row)
+struct SmallLds {
+    double cdf[kTile];
+    float x[kTile], y[kTile], z[kTile], th[kTile];
+    double red[4 * 4];
+    double scan[4];
+    SmallDecision dec;
+};
+
+// Weight pass + decision + in-register resample/normalise of one small filter of n <= 1024 particles held four
+// per thread in `r` (sn/cs = sin/cos of their headings).  (cx,cy,cz) is the respawn centre; index0 the Philox
+// index of particle 0.  Returns the decision (valid in every thread).
+__device__ __forceinline__ SmallDecision small_filter_update(Row4& r, const float (&sn)[4], const float (&cs)[4], int j0, int n,
+                                                             SmallLds& L, const RngKey& key, uint64_t index0, uint64_t rsIndex,
+                                                             float range, float stdRange, bool allowSpawn, bool force,
+                                                             float cx, float cy, float cz)
+{
+    // pfResample.c:93-106 / :151-164: float products, added in double; inclusive CDF by a block scan
+    double acc[4] = { 0, 0, 0, 0 };     // (unused), ss, c, sn
+    double a[4];
+    double run = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float wi = (j0 + k < n) ? r.w[k] : 0.0f;
+        run += wi;
+        a[k] = run;
+        acc[1] += wi * wi;
+        acc[2] += wi * cs[k];
+        acc[3] += wi * sn[k];
+    }
+    double total;
+    const double incl = block_inclusive_scan(run, L.scan, total);
+    const double off = incl - run;
+    const double inf = __builtin_huge_val();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = j0 + k;
+        L.cdf[j] = (j < n) ? off + a[k] : inf;
+        L.x[j] = r.x[k]; L.y[j] = r.y[k]; L.z[j] = r.z[k]; L.th[j] = r.th[k];
+    }
+    block_sum<4>(acc, L.red);
+    if (threadIdx.x == 0) L.dec = small_decide(total, acc[1], acc[2], acc[3], n, range, allowSpawn, force, key, rsIndex);
+    __syncthreads();
+    const SmallDecision d = L.dec;
+    if (d.resample) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = j0 + k;
+            if (i >= n) continue;
+            if (i < d.numSpawn) {
+                spawn_from_range(key, index0 + (uint64_t)i, cx, cy, cz, range, stdRange, r.x[k], r.y[k], r.z[k], r.th[k]);
+            } else {
+                const double u = d.rStart + d.rStep * (double)i;        // pfResample.c:117 / :180
+                const int j = upper_bound_tile(L.cdf, n, u);
+                spawn_from_other(key, index0 + (uint64_t)i, L.x[j], L.y[j], L.z[j], L.th[j], kHxyz, d.htheta,
+                                 r.x[k], r.y[k], r.z[k], r.th[k]);
+            }
+            r.w[k] = 1.0f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (j0 + k < n) r.w[k] *= d.m;              // pfResample.c:133-137 / :195-199
+    }
+    return d;
+}
+
+// ------------------------------------------------------------------ gate of the measured beacon
+__global__ __launch_bounds__(kThreads) void k_slam_gate(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
+                                                       const Motion* __restrict__ bcnMo, float* __restrict__ rowSum)
+{
+    const int f = blockIdx.y, i = blockIdx.x;
+    const SlamStep st = many ? many[f] : one;
+    if (st.mode != 1) return;
+    __shared__ double red[4];
+
+    // tag particle i after its VIO motion (stored by k_slam_tag, which runs after every row has read the old one)
+    const size_t ti = (size_t)f * D.tagStride + i;
+    float tx = P.tag[1][ti], ty = P.tag[2][ti], tz = P.tag[3][ti], tth = P.tag[4][ti];
+    if (st.tagMoving) {
+        float sn, cs;
+        motion_particle(RngKey{ st.seed, 0u, st.epoch }, (uint64_t)i, st.tagMo, st.tagMo.stdTheta <= 1e-4f, tx, ty, tz, tth, sn, cs);
+    }
+
+    const int c = st.target, n = D.nBcn, j0 = threadIdx.x * 4;
+    const size_t base = slam_row_base(D, f, c, i);
+    const float* const src[5] = { P.bcn[0], P.bcn[1], P.bcn[2], P.bcn[3], P.bcn[4] };
+    Row4 r;
+    row_load(src, base, j0, n, r);
+    const bool moving = (st.movingMask >> c) & 1u;
+    Motion mo{};
+    if (moving) mo = bcnMo[(size_t)f * D.maxBcns + c];
+    const bool smallTurn = mo.stdTheta <= 1e-4f;
+    const RngKey key{ st.seed, (uint32_t)(c + 1), st.epoch };
+    bool thetaChanged = false;
+    double sum[1] = { 0.0 };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = j0 + k;
+        if (j >= n) continue;
+        if (moving) {
+            float sn, cs;
+            motion_particle(key, (uint64_t)i * n + j, mo, smallTurn, r.x[k], r.y[k], r.z[k], r.th[k], sn, cs);
+        } else {
+            const float t2 = wrap_two_pi(r.th[k]);
+            thetaChanged |= (t2 != r.th[k]);
+            r.th[k] = t2;
+        }
+        // pfMeasurement.c:142-147
+        const float dx = tx - r.x[k], dy = ty - r.y[k], dz = tz - r.z[k];
+        const float pRange = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (fabsf(pRange - st.range) > st.thresh) r.w[k] *= st.minWeight;
+        sum[0] += r.w[k];
+    }
+    row_store1(P.bcn[0], base, j0, n, r.w);
+    if (moving) {
+        row_store1(P.bcn[1], base, j0, n, r.x);
+        row_store1(P.bcn[2], base, j0, n, r.y);
+        row_store1(P.bcn[3], base, j0, n, r.z);
+        row_store1(P.bcn[4], base, j0, n, r.th);
+    } else if (thetaChanged) {
+        row_store1(P.bcn[4], base, j0, n, r.th);
+    }
+    block_sum<1>(sum, red);
+    if (threadIdx.x == 0) rowSum[(size_t)f * D.nTag + i] = (float)sum[0];      // pfMeasurement.c:148-150: tp->w *= bcnSum
+}
+
+// ------------------------------------------------------------------ the tag particles of every filter
+__global__ __launch_bounds__(kThreads) void k_slam_tag(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
+                                                      const float* __restrict__ rowSum, int* __restrict__ tagBranch)
+{
+    const int f = blockIdx.x;
+    const SlamStep st = many ? many[f] : one;
+    if (st.mode == 0) return;
+    __shared__ SmallLds L;
+
+    const int n = D.nTag, j0 = threadIdx.x * 4;
+    const size_t base = (size_t)f * D.tagStride;
+    const float* const src[5] = { P.tag[0], P.tag[1], P.tag[2], P.tag[3], P.tag[4] };
+    Row4 r;
+    row_load(src, base, j0, n, r);
+    const RngKey key{ st.seed, 0u, st.epoch };
+    const bool smallTurn = st.tagMo.stdTheta <= 1e-4f;
+    float sn[4] = { 0, 0, 0, 0 }, cs[4] = { 1, 1, 1, 1 };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = j0 + k;
+        if (j >= n) continue;
+        if (st.tagMoving) {
+            motion_particle(key, (uint64_t)j, st.tagMo, smallTurn, r.x[k], r.y[k], r.z[k], r.th[k], sn[k], cs[k]);
+        } else {
+            r.th[k] = wrap_two_pi(r.th[k]);
+            sincos_bounded(r.th[k], sn[k], cs[k]);
+        }
+        if (st.mode == 1) r.w[k] *= rowSum[(size_t)f * D.nTag + j];
+    }
+    int branch = 0;
+    if (st.mode == 1) {
+        // pfResample.c:86-139 on the tag particles: no respawn, never forced
+        const SmallDecision d = small_filter_update(r, sn, cs, j0, n, L, key, 0, 0, st.range, st.stdRange, false, false, 0.f, 0.f, 0.f);
+        branch = d.resample;
+    }
+    row_store1(P.tag[0], base, j0, n, r.w);
+    row_store1(P.tag[1], base, j0, n, r.x);
+    row_store1(P.tag[2], base, j0, n, r.y);
+    row_store1(P.tag[3], base, j0, n, r.z);
+    row_store1(P.tag[4], base, j0, n, r.th);
+    if (threadIdx.x == 0) tagBranch[f] = branch;
+}
+
+// ------------------------------------------------------------------ beacon rows: motion, spawn, _resampleBcn
+__global__ __launch_bounds__(kThreads) void k_slam_rows(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
+                                                       const Motion* __restrict__ bcnMo, const int* __restrict__ tagBranch)
+{
+    const int f = blockIdx.z, c = blockIdx.y, k = blockIdx.x;
+    const SlamStep st = many ? many[f] : one;
+    if (st.mode == 0) return;
+    const bool isTarget = c == st.target;
+    const bool active = (st.activeMask >> c) & 1u;     // one of allBcns[]: takes the VIO commit and a forced resample
+    if (!active && !isTarget) return;
+    const int n = D.nBcn, j0 = threadIdx.x * 4;
+    const size_t base = slam_row_base(D, f, c, k);
+    const RngKey key{ st.seed, (uint32_t)(c + 1), st.epoch };
+    const size_t ti = (size_t)f * D.tagStride + k;
+
+    if (st.mode == 2 && isTarget) {
+        // pfInit.c:34-45: the beacon's particles on the range shell around each (moved) tag particle
+        const float tx = P.tag[1][ti], ty = P.tag[2][ti], tz = P.tag[3][ti];
+        Row4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j0 + q;
+            r.w[q] = 0.f; r.x[q] = 0.f; r.y[q] = 0.f; r.z[q] = 0.f; r.th[q] = 0.f;
+            if (j >= n) continue;
+            spawn_from_range(key, (uint64_t)k * n + j, tx, ty, tz, st.range, st.stdRange, r.x[q], r.y[q], r.z[q], r.th[q]);
+            r.w[q] = 1.0f;
+        }
+        row_store1(P.bcn[0], base, j0, n, r.w);
+        row_store1(P.bcn[1], base, j0, n, r.x);
+        row_store1(P.bcn[2], base, j0, n, r.y);
+        row_store1(P.bcn[3], base, j0, n, r.z);
+        row_store1(P.bcn[4], base, j0, n, r.th);
+        return;
+    }
+    if (!((st.initMask >> c) & 1u)) return;     // not yet spawned: nothing to move (the spawn overwrites it all)
+
+    // the measured beacon's motion was applied by k_slam_gate
+    const bool moving = ((st.movingMask >> c) & 1u) && !(isTarget && st.mode == 1);
+    const int tb = tagBranch[f];
+    // pfResample.c:122-137: tag particles resampled -> every initialised beacon, forced; else the measured one
+    const bool takes = st.mode == 1 && (tb != 0 ? active : isTarget);
+    if (!moving && !takes) return;
+
+    __shared__ SmallLds L;
+    const float* const src[5] = { P.bcn[0], P.bcn[1], P.bcn[2], P.bcn[3], P.bcn[4] };
+    Row4 r;
+    row_load(src, base, j0, n, r);
+    Motion mo{};
+    if (moving) mo = bcnMo[(size_t)f * D.maxBcns + c];
+    const bool smallTurn = mo.stdTheta <= 1e-4f;
+    float sn[4] = { 0, 0, 0, 0 }, cs[4] = { 1, 1, 1, 1 };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        if (j >= n) continue;
+        if (moving) {
+            motion_particle(key, (uint64_t)k * n + j, mo, smallTurn, r.x[q], r.y[q], r.z[q], r.th[q], sn[q], cs[q]);
+        } else {
+            r.th[q] = wrap_two_pi(r.th[q]);
+            sincos_bounded(r.th[q], sn[q], cs[q]);
+        }
+    }
+    if (takes) {
+        const float tx = P.tag[1][ti], ty = P.tag[2][ti], tz = P.tag[3][ti];   // respawn centre: tag particle k as it is NOW
+        small_filter_update(r, sn, cs, j0, n, L, key, (uint64_t)k * n, (uint64_t)k, st.range, st.stdRange, true, tb != 0, tx, ty, tz);
+        row_store1(P.bcn[0], base, j0, n, r.w);
+    }
+    row_store1(P.bcn[1], base, j0, n, r.x);
+    row_store1(P.bcn[2], base, j0, n, r.y);
+    row_store1(P.bcn[3], base, j0, n, r.z);
+    row_store1(P.bcn[4], base, j0, n, r.th);
+}
+
+// ------------------------------------------------------------------ pose estimates
+// particleFilter.c:302-333: sums of w, wx, wy, wz, w cos, w sin over the tag particles of each filter
+__global__ __launch_bounds__(kThreads) void k_slam_tag_pose(SlamPtrs P, SlamDims D, double* __restrict__ tagPose)
+{
+    __shared__ double red[4 * 6];
+    const int f = blockIdx.x, n = D.nTag, j0 = threadIdx.x * 4;
+    const float* const src[5] = { P.tag[0], P.tag[1], P.tag[2], P.tag[3], P.tag[4] };
+    Row4 r;
+    row_load(src, (size_t)f * D.tagStride, j0, n, r);
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (j0 + k >= n) continue;
+        float sn, cs;
+        sincos_bounded(r.th[k], sn, cs);
+        const float w = r.w[k];
+        acc[0] += w; acc[1] += w * r.x[k]; acc[2] += w * r.y[k]; acc[3] += w * r.z[k]; acc[4] += w * cs; acc[5] += w * sn;
+    }
+    block_sum<6>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) tagPose[(size_t)f * 6 + k] = acc[k];
+    }
+}
+
+// particleFilter.c:353-378, inner loop: per tag particle i the weighted sums of its beacon row, folded into the
+// row's contribution w1 * (sum2 / s2) exactly as the reference forms it (float), -> rowTerms[f][i][6]
+__global__ __launch_bounds__(kThreads) void k_slam_bcn_rows_pose(SlamPtrs P, SlamDims D, const int* __restrict__ slotOf,
+                                                                float* __restrict__ rowTerms)
+{
+    __shared__ double red[4 * 6];
+    const int f = blockIdx.y, i = blockIdx.x, n = D.nBcn, j0 = threadIdx.x * 4;
+    const int c = slotOf[f];
+    if (c < 0) return;
+    const float* const src[5] = { P.bcn[0], P.bcn[1], P.bcn[2], P.bcn[3], P.bcn[4] };
+    Row4 r;
+    row_load(src, slam_row_base(D, f, c, i), j0, n, r);
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (j0 + k >= n) continue;
+        float sn, cs;
+        sincos_bounded(r.th[k], sn, cs);
+        const float w = r.w[k];
+        acc[0] += w; acc[1] += w * r.x[k]; acc[2] += w * r.y[k]; acc[3] += w * r.z[k]; acc[4] += w * cs; acc[5] += w * sn;
+    }
+    block_sum<6>(acc, red);
+    if (threadIdx.x == 0) {
+        const float w1 = P.tag[0][(size_t)f * D.tagStride + i];
+        const float s2 = (float)acc[0];
+        float* o = rowTerms + ((size_t)f * D.nTag + i) * 6;
+        o[0] = w1;
+#pragma unroll
+        for (int k = 1; k < 6; ++k) o[k] = w1 * (float)acc[k] / s2;
+    }
+}
+
+// ... outer loop: sums over the tag particles -> bcnPose[f][6]
+__global__ __launch_bounds__(kThreads) void k_slam_bcn_pose(SlamDims D, const int* __restrict__ slotOf, const float* __restrict__ rowTerms,
+                                                           double* __restrict__ bcnPose)
+{
+    __shared__ double red[4 * 6];
+    const int f = blockIdx.x;
+    if (slotOf[f] < 0) return;
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int i = threadIdx.x; i < D.nTag; i += kThreads) {
+        const float* o = rowTerms + ((size_t)f * D.nTag + i) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += o[k];
+    }
+    block_sum<6>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bcnPose[(size_t)f * 6 + k] = acc[k];
+    }
+}
+
+// tag particles of freshly initialised filters: origin, w = 1, theta = 0 (pfInit.c:27-32, 47-54)
+__global__ void k_slam_tag_init(SlamPtrs P, SlamDims D, int f0, int count)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * D.tagStride) return;
+    const size_t p = (size_t)f0 * D.tagStride + idx;
+    const int j = idx % D.tagStride;
+    P.tag[0][p] = j < D.nTag ? 1.0f : 0.0f;
+    P.tag[1][p] = 0.f; P.tag[2][p] = 0.f; P.tag[3][p] = 0.f; P.tag[4][p] = 0.f;
+}
+
+}  // namespace pf

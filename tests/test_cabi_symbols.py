@@ -1,0 +1,68 @@
+"""The C-ABI library loads without a GPU and exports every function include/*.h declares; the reference-layout
+structs keep the reference's sizes and offsets (400 056 / 4 056 / 2 020 056 bytes).  No compute."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+
+
+def _declared_functions():
+    names = []
+    for h in ("particleFilter.h", "pfx.h"):
+        src = open(os.path.join(INC, h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"^\s*#.*$", "", src, flags=re.M)
+        for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", src):
+            names.append(m.group(1))
+    return sorted(set(names))
+
+
+def test_headers_declare_the_reference_entry_points():
+    names = _declared_functions()
+    for fn in ("particleFilterSeed_set", "particleFilterLoc_init", "particleFilterSlam_init", "particleFilterSlam_addBcn",
+               "particleFilterLoc_depositVio", "particleFilterSlam_depositTagVio", "particleFilterSlam_depositBcnVio",
+               "particleFilterLoc_depositRange", "particleFilterSlam_depositRange", "particleFilterLoc_depositRssi",
+               "particleFilterSlam_depositRssi", "particleFilterLoc_getTagLoc", "particleFilterSlam_getTagLoc",
+               "particleFilterSlam_getBcnLoc"):
+        assert fn in names          # the 14 functions of the reference's particleFilter.h:26,102-114
+    assert len(names) > 80
+
+
+def test_library_exports_every_declared_symbol():
+    from slam3d_amd import _lib
+    L = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in _declared_functions() if not hasattr(L, n)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    for g in ("PF_SEED", "PF_SEED_SET"):        # pfRandom.h:20-21
+        C.c_uint.in_dll(L, g)
+    assert _lib.lib().pfx_version().startswith(b"slam3d_amd")
+
+
+def test_struct_layout_matches_reference(tmp_path):
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pfx.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(particleFilterLoc_t), sizeof(particleFilterSlam_t),'
+                   ' sizeof(bcn_t), offsetof(particleFilterLoc_t, initialized), offsetof(particleFilterLoc_t, firstT),'
+                   ' offsetof(particleFilterLoc_t, lastX), offsetof(particleFilterSlam_t, initialized), offsetof(bcn_t, initialized));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", INC, "-o", str(exe), str(src)])     # plain C, as the reference's callers
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert [int(v) for v in out] == [400056, 4056, 2020056, 400000, 400008, 400040, 4000, 2020000]
+
+
+def test_no_device_means_loud_failure():
+    """Without a GPU every create fails with a message (no CPU fallback exists behind the product API)."""
+    from slam3d_amd import _lib, particlefilter as pfm
+    if pfm.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.PfxError):
+        pfm.DeviceParticleFilterLoc(1000, seed=1)
+    from slam3d_amd import slam
+    with pytest.raises(_lib.PfxError):
+        slam.DeviceSlamBatch(1, 10, 10)
