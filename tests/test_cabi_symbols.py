@@ -66,3 +66,17 @@ def test_no_device_means_loud_failure():
     from slam3d_amd import slam
     with pytest.raises(_lib.PfxError):
         slam.DeviceSlamBatch(1, 10, 10)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/test"), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize("src", ["test/test.c", "csvlocalize/csvlocalize.c", "csvslam/csvslam.c"])
+def test_reference_callers_link_unchanged(tmp_path, src):
+    """The reference's own C callers compile against include/particleFilter.h and link against the library with
+    no source change.  Compile + link only: running needs a GPU."""
+    from slam3d_amd import _lib
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "caller"
+    subprocess.check_call(["gcc", "-O2", "-w", "-o", str(exe), "-I", INC, os.path.join("/root/reference", src),
+                           "-L", libdir, "-lparticlefilter", "-lm", f"-Wl,-rpath,{libdir}"])
+    out = subprocess.check_output(["nm", "-u", str(exe)]).decode()
+    assert "particleFilter" in out      # resolved from the shared library, not compiled in
