@@ -360,6 +360,13 @@ __device__ __forceinline__ long long first_offspring_at(double b, double rStart,
 // x,y,z,theta of the offspring below this shard's own index range first, then those above it.
 struct StagePtrs { float* a[4]; };
 
+// Structure (measured, MI355X, N = 16 M): a version that gathered the ancestors from global memory with one dword
+// load per lane and stored one dword per lane and array ran at 0.14 ms whatever was left of its arithmetic; the
+// access shape was the bound.  Here every byte moves as a float4: the tile's w,x,y,z,theta are loaded with five
+// float4 loads per thread issued together (one memory latency per workgroup), the ancestors wait in LDS, and each
+// thread produces FOUR CONSECUTIVE offspring, aligned on a 4-element boundary of the destination arrays, so that
+// it stores five float4.  The first and last group of a tile (shared with the neighbouring workgroups) and
+// offspring that go to another shard's staging area take dword stores.
 template <bool RECORD>
 __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const LocCtl* __restrict__ ctl,
                                                           const double* __restrict__ chunkBase,
@@ -371,9 +378,19 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
     if (ctl->branch != 1) return;           // normalise-only step: nothing to do (wave-uniform exit)
 
     __shared__ double cdf[kTile];
+    __shared__ float4 anc[kTile];           // x y z theta of the tile's particles
     __shared__ double red[4];
     __shared__ long long span[2];
     const int t = blockIdx.x, tid = threadIdx.x;
+    const int src = ctl->src, dst = ctl->dst;
+    const long long tbase = (long long)t * kTile;
+    const long long e0 = tbase + tid * kPerThread;
+    const float4 w4 = *reinterpret_cast<const float4*>(bufs.a[src][0] + e0);
+    const float4 x4 = *reinterpret_cast<const float4*>(bufs.a[src][1] + e0);
+    const float4 y4 = *reinterpret_cast<const float4*>(bufs.a[src][2] + e0);
+    const float4 z4 = *reinterpret_cast<const float4*>(bufs.a[src][3] + e0);
+    const float4 t4 = *reinterpret_cast<const float4*>(bufs.a[src][4] + e0);
+
     const double rStart = ctl->rStart, rStep = ctl->rStep;
     const double shardBase = ctl->shardBase, shardEnd = ctl->shardEnd;
     const double tileStart = tile_start_cdf(chunkBase, tileIncl, t, shardBase, shardEnd);
@@ -390,9 +407,6 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
     }
 
     // this tile's CDF, rebuilt from the weights (pfResample.c:45,49 in double): tile start + inclusive scan
-    const int src = ctl->src, dst = ctl->dst;
-    const long long tbase = (long long)t * kTile;
-    const float4 w4 = *reinterpret_cast<const float4*>(bufs.a[src][0] + tbase + tid * kPerThread);
     const double a0 = w4.x, a1 = a0 + w4.y, a2 = a1 + w4.z, a3 = a2 + w4.w;
     double total;
     const double incl = block_inclusive_scan(a3, red, total);
@@ -404,45 +418,90 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
     cdf[tid * 4 + 1] = (tid * 4 + 1 < nValid) ? off + a1 : inf;
     cdf[tid * 4 + 2] = (tid * 4 + 2 < nValid) ? off + a2 : inf;
     cdf[tid * 4 + 3] = (tid * 4 + 3 < nValid) ? off + a3 : inf;
+    anc[tid * 4 + 0] = make_float4(x4.x, y4.x, z4.x, t4.x);
+    anc[tid * 4 + 1] = make_float4(x4.y, y4.y, z4.y, t4.y);
+    anc[tid * 4 + 2] = make_float4(x4.z, y4.z, z4.z, t4.z);
+    anc[tid * 4 + 3] = make_float4(x4.w, y4.w, z4.w, t4.w);
     __syncthreads();
     const long long i0 = span[0], i1 = span[1];
     if (i0 >= i1) return;
 
-    const float* __restrict__ sx = bufs.a[src][1];
-    const float* __restrict__ sy = bufs.a[src][2];
-    const float* __restrict__ sz = bufs.a[src][3];
-    const float* __restrict__ st = bufs.a[src][4];
-    float* __restrict__ dw = bufs.a[dst][0];
-    float* __restrict__ dx = bufs.a[dst][1];
-    float* __restrict__ dy = bufs.a[dst][2];
-    float* __restrict__ dz = bufs.a[dst][3];
-    float* __restrict__ dt = bufs.a[dst][4];
-
     const float hTheta = ctl->htheta;
-    const int numSpawn = ctl->numSpawn;
+    const long long numSpawn = ctl->numSpawn;
     const long long selfBegin = ctl->selfBegin, selfEnd = ctl->selfEnd, outBegin = ctl->outBegin;
     const long long outEnd = ctl->outEnd;
     // staged offspring: those below the shard's own range first, then those above it
     const long long below = selfBegin > outBegin ? (selfBegin < outEnd ? selfBegin : outEnd) - outBegin : 0;
     const long long aboveStart = selfEnd > outBegin ? selfEnd : outBegin;
 
-    for (long long i = i0 + tid; i < i1; i += kThreads) {
-        const double u = rStart + rStep * (double)i;        // pfResample.c:71
-        const int j = upper_bound_tile(cdf, nValid, u);
-        const long long a = tbase + j;
-        float x, y, z, th;
-        if (i < numSpawn) {
-            spawn_from_range(key, (uint64_t)i, bx, by, bz, range, stdRange, x, y, z, th);   // pfResample.c:75-76
-        } else {
-            spawn_from_other(key, (uint64_t)i, sx[a], sy[a], sz[a], st[a], kHxyz, hTheta, x, y, z, th);
-        }
-        if (i >= selfBegin && i < selfEnd) {
-            const long long p = i - selfBegin;
-            dw[p] = 1.0f; dx[p] = x; dy[p] = y; dz[p] = z; dt[p] = th;
-            if (RECORD) ancOut[p] = (int)a;
-        } else {
-            const long long p = (i < selfBegin) ? i - outBegin : (i - aboveStart) + below;
-            stage.a[0][p] = x; stage.a[1][p] = y; stage.a[2][p] = z; stage.a[3][p] = th;
+    // Offspring i = cb + k with k a 32-bit offset inside the chunk [cb, ce): everything per offspring is 32-bit, the
+    // 64-bit parts are wave-uniform.  (One tile owns more than 2^30 offspring only if nearly all the weight of a huge
+    // sharded filter sits in it; the outer loop covers that.)
+    constexpr long long kSpan = 1ll << 30;
+    for (long long cb = i0; cb < i1; cb += kSpan) {
+        const long long ce = (i1 - cb < kSpan) ? i1 : cb + kSpan;
+        const int cnt = (int)(ce - cb);
+        auto clampk = [&](long long v) -> int { v -= cb; return v < 0 ? 0 : (v > cnt ? cnt : (int)v); };
+        const int kSpawn = clampk(numSpawn), kSelfB = clampk(selfBegin), kSelfE = clampk(selfEnd);
+        const double dCb = (double)cb;                      // exact (< 2^53), and so is dCb + k
+        const long long so = cb - selfBegin;                // element of the own arrays that offspring cb goes to
+        // groups of four offspring aligned on the destination arrays: element (so + k) % 4 == 0 starts a group
+        const int lead = (int)(((so % 4) + 4) % 4);         // elements of the first group that precede cb
+        const int groups = (cnt + lead + 3) / 4;
+        float* __restrict__ dw = bufs.a[dst][0] + so;
+        float* __restrict__ dx = bufs.a[dst][1] + so;
+        float* __restrict__ dy = bufs.a[dst][2] + so;
+        float* __restrict__ dz = bufs.a[dst][3] + so;
+        float* __restrict__ dt = bufs.a[dst][4] + so;
+        int* __restrict__ da = RECORD ? ancOut + so : nullptr;
+        const long long lo = cb - outBegin, hi = cb - aboveStart + below;
+        const int fullB = kSelfB > 0 ? kSelfB : 0, fullE = kSelfE < cnt ? kSelfE : cnt;
+        for (int g = tid; g < groups; g += kThreads) {
+            const int k0 = 4 * g - lead;                    // offsets k0 .. k0+3 (k0 may be negative in group 0)
+            int jj[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const double u = rStart + rStep * (dCb + (double)(k0 + m));     // pfResample.c:71 with i = cb + k
+                jj[m] = upper_bound_tile(cdf, nValid, u);
+            }
+            float ox[4], oy[4], oz[4], ot[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int k = k0 + m;
+                ox[m] = oy[m] = oz[m] = ot[m] = 0.0f;
+                if (k < 0 || k >= cnt) continue;
+                const uint64_t i = (uint64_t)(cb + k);
+                if (k < kSpawn) {
+                    spawn_from_range(key, i, bx, by, bz, range, stdRange, ox[m], oy[m], oz[m], ot[m]);  // pfResample.c:75-76
+                } else {
+                    const float4 a = anc[jj[m]];
+                    spawn_from_other(key, i, a.x, a.y, a.z, a.w, kHxyz, hTheta, ox[m], oy[m], oz[m], ot[m]);
+                }
+            }
+            if (k0 >= fullB && k0 + 3 < fullE) {
+                *reinterpret_cast<float4*>(dw + k0) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                *reinterpret_cast<float4*>(dx + k0) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+                *reinterpret_cast<float4*>(dy + k0) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+                *reinterpret_cast<float4*>(dz + k0) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+                *reinterpret_cast<float4*>(dt + k0) = make_float4(ot[0], ot[1], ot[2], ot[3]);
+                if (RECORD) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) da[k0 + m] = (int)(tbase + jj[m]);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int k = k0 + m;
+                    if (k < 0 || k >= cnt) continue;
+                    if (k >= kSelfB && k < kSelfE) {
+                        dw[k] = 1.0f; dx[k] = ox[m]; dy[k] = oy[m]; dz[k] = oz[m]; dt[k] = ot[m];
+                        if (RECORD) da[k] = (int)(tbase + jj[m]);
+                    } else {
+                        const long long p = (k < kSelfB ? lo : hi) + k;
+                        stage.a[0][p] = ox[m]; stage.a[1][p] = oy[m]; stage.a[2][p] = oz[m]; stage.a[3][p] = ot[m];
+                    }
+                }
+            }
         }
     }
 }
