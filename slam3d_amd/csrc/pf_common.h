@@ -40,8 +40,14 @@ __host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // three-input xor in one instruction (v_bitop3_b32, truth table 0x96); the compiler does not form it itself
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+#else
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
         const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+#endif
         c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -105,16 +111,19 @@ __device__ __forceinline__ float log_unit(float u)
     return h + l;
 }
 
-// pfRandom.c:67-74 -- Box-Muller pair from two words (u1 first).  The square root is the hardware's
-// (1 ulp, not correctly rounded): the result only ever scales a noise term of at most 0.1 m.
+// pfRandom.c:67-74 -- Box-Muller pair from two words (u1 first):  f = sqrt(-2 ln u1),  (f cos 2 pi u2, f sin 2 pi u2).
+// Everything here is a hardware transcendental: v_log_f32 (log2; measured on MI355X over u in (0,1]: 1.6e-7
+// relative after the multiplication by ln 2), v_sqrt_f32 (1 ulp), and v_sin_f32 / v_cos_f32, which take their
+// argument in REVOLUTIONS -- u2 itself, no multiplication by 2 pi and no range reduction; measured maximum absolute
+// error 1.25e-7 over all 2^24 arguments k / 2^24 (tools/dev/hwsincos.hip).  The reference rounds g = u2 * 2 pi to
+// float before taking sinf/cosf, which moves the angle by up to 3.7e-7 rad: the two ways agree to about 4e-7
+// absolute in the unit normal, i.e. 4e-8 m after the 0.1 m jitter scale, 4e-10 m after the VIO noise scale.
 __device__ __forceinline__ void normal2(uint32_t w0, uint32_t w1, float& a, float& b)
 {
-    const float f = __builtin_amdgcn_sqrtf(-2.0f * log_unit(uniform_nonzero(w0)));
-    const float g = uniform_nonzero(w1) * 2.0f * kPi;
-    float sn, cs;
-    sincos_bounded(g, sn, cs);
-    a = f * cs;
-    b = f * sn;
+    const float f = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(uniform_nonzero(w0)) * -1.38629436111989061883f);   // -2 ln 2
+    const float u2 = uniform_nonzero(w1);
+    a = f * __builtin_amdgcn_cosf(u2);
+    b = f * __builtin_amdgcn_sinf(u2);
 }
 
 // fmodf(x, 2*pi_f) with the result keeping x's sign (pfMeasurement.c:47, pfInit.c:78).  For
