@@ -382,3 +382,25 @@ def test_test1_replay_statistically_equivalent(pfm, test1):
     dth = np.angle(np.exp(1j * (got[100:, 4] - exp[100:, 4])))
     assert np.sqrt((dth ** 2).mean()) < 0.42
     assert np.linalg.norm(got[-1, 1:4] - exp[-1, 1:4]) < 0.10
+
+
+def test_config2_range_only_1m(pfm, test1):
+    """BASELINE.json configs[1]: the csvlocalize trace (sampledata/arena == test/data) with the filter
+    scaled up to N = 2^20 particles, range rows only.  No VIO row -> every deposit commits a zero delta and the motion
+    kernel is elided (only the weights are rewritten).  The final position must sit inside the seed-to-seed spread of
+    the reference filter at N = 10 000 on the same range-only replay: mean (-0.6065, 3.2254, 1.9666), std
+    (0.0037, 0.0013, 0.0083) over 12 rand_r seeds (tests/tools/range_only_spread.py); bounds = 5 std + 5 mm.
+    The heading is unobservable without motion (uniform over the seeds) and is not checked."""
+    from slam3d_amd import replay as R
+    vio, uwb, dep = test1
+    g = pfm.DeviceParticleFilterLoc(1 << 20, seed=SEED)
+    g.profile_begin(4096)
+    res = R.replay_loc(g, vio, uwb, dep, range_only=True)
+    assert res.n_vio == 0 and res.n_range > 900
+    prof = g.profile_read()
+    assert prof["stream"]["launches"] == 0 and prof["stream_static"]["launches"] == res.n_range - 1
+    ok, _t, x, y, z, _th = g.getTagLoc()
+    assert ok == 1
+    assert abs(float(x) + 0.6065) < 0.0235 and abs(float(y) - 3.2254) < 0.0115 and abs(float(z) - 1.9666) < 0.0465
+    w = g.download()[0]
+    assert np.isfinite(w).all() and w.min() >= 0.0
