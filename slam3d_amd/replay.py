@@ -135,3 +135,107 @@ def load_test1(folder: str):
     return (read_vio(os.path.join(folder, VIO_FILE)),
             read_uwb(os.path.join(folder, UWB_FILE)),
             read_deployment(os.path.join(folder, DEPLOY_FILE)))
+
+
+# ------------------------------------------------------------------ csvslam: verbose trace format, SLAM replay
+# csvslam/csvslam.c:16-27
+SLAM_NUM_BCNS = 12
+SLAM_UWB_STD = f32(0.1)
+SLAM_UWB_BIAS = f32(0.4)
+
+
+def _skip_to_waypoint(rows, key):
+    """csvslam.c:104-116 / :125-135: the FIRST read skips rows while the first character of the waypoint field is < '4'
+    (a character comparison: waypoints 10..19 would count as '1'; the skip only runs once, at the start)."""
+    k = 0
+    while k < len(rows) and key(rows[k]) < "4":
+        k += 1
+    return rows[k:]
+
+
+def read_vio_verbose(path: str, skip_to_waypoint: bool = True):
+    """Line pairs ``t,position,waypoint,accuracy,y,z,x`` / ``t,orientation,...`` -> (t, x, y, z) (csvslam.c:97-119)."""
+    rows = []
+    with open(path, "r") as fh:
+        lines = fh.read().split("\n")
+    k = 0
+    while k < len(lines) and lines[k]:
+        c = lines[k].split(",")
+        rows.append((float(c[0]), f32(float(c[6])), f32(float(c[4])), f32(float(c[5])), c[2][0]))
+        k += 2                                   # the orientation line is skipped unread (csvslam.c:113)
+    if skip_to_waypoint:
+        rows = _skip_to_waypoint(rows, lambda r: r[4])
+    return [r[:4] for r in rows]
+
+
+def read_uwb_verbose(path: str, skip_to_waypoint: bool = True, num_bcns: int = SLAM_NUM_BCNS):
+    """Rows ``t,uwb_range,waypoint,<beacon name>,range,...`` -> (t, beacon, range); the beacon is the first letter of
+    its host name minus 'a' (csvslam.c:121-140)."""
+    rows = []
+    with open(path, "r") as fh:
+        for line in fh:
+            c = line.rstrip("\n").split(",")
+            if len(c) < 5:
+                continue
+            b = ord(c[3][0]) - ord("a")
+            if not 0 <= b < num_bcns:
+                raise ValueError(f"beacon {c[3]!r} out of range in {path}")          # the reference asserts (csvslam.c:138)
+            rows.append((float(c[0]), b, f32(float(c[4])), c[2][0]))
+    if skip_to_waypoint:
+        rows = _skip_to_waypoint(rows, lambda r: r[3])
+    return [r[:3] for r in rows]
+
+
+def format_bcn_row(b: int, x, y, z, theta) -> str:
+    """csvslam.c:158: ``%hhu,%f,%f,%f,%f``"""
+    return "%d,%f,%f,%f,%f\n" % (int(b), float(x), float(y), float(z), float(theta))
+
+
+@dataclass
+class SlamReplayResult:
+    tag_rows: List[Tuple[float, float, float, float, float]] = field(default_factory=list)   # t,x,y,z,theta per VIO row
+    bcn_rows: List[Tuple[int, float, float, float, float]] = field(default_factory=list)     # b,x,y,z,theta at the end
+    n_vio: int = 0
+    n_range: int = 0
+
+    def tag_csv(self) -> str:
+        # csvslam.c:142-151 prints t,x,y,z,theta in THIS order (unlike test.c, which un-permutes to the file's y,z,x)
+        return "t,x,y,z,theta\n" + "".join("%f,%f,%f,%f,%f\n" % tuple(float(v) for v in r) for r in self.tag_rows)
+
+    def bcn_csv(self) -> str:
+        return "b,x,y,z,theta\n" + "".join(format_bcn_row(*r) for r in self.bcn_rows)
+
+
+def replay_slam(pf, bcns: Sequence, vio: Sequence, uwb: Sequence, uwb_bias=SLAM_UWB_BIAS, uwb_std=SLAM_UWB_STD,
+                max_events: Optional[int] = None) -> SlamReplayResult:
+    """csvslam.c:62-85: merge the traces by timestamp; VIO rows go to depositTagVio followed by a getTagLoc, range rows
+    (minus the bias, if in (0, 30) m) to depositRange on the named beacon with every beacon in allBcns; at the end one
+    getBcnLoc per beacon.  ``pf`` / ``bcns`` need the interface of slam3d_amd.slam.ParticleFilterSlam / its beacons."""
+    res = SlamReplayResult()
+    iv = iu = 0
+    nv, nu = len(vio), len(uwb)
+    events = 0
+    while iv < nv or iu < nu:
+        if max_events is not None and events >= max_events:
+            break
+        events += 1
+        if iv < nv and (iu >= nu or vio[iv][0] < uwb[iu][0]):
+            t, x, y, z = vio[iv]
+            iv += 1
+            pf.depositTagVio(t, x, y, z, 0.0)
+            res.n_vio += 1
+            st = pf.getTagLoc()
+            if st[0]:
+                res.tag_rows.append(tuple(st[1:]))
+        else:
+            t, b, r = uwb[iu]
+            iu += 1
+            r = f32(r - f32(uwb_bias))
+            if r > f32(0.0) and r < f32(30.0):
+                pf.depositRange(bcns[b], r, f32(uwb_std))
+                res.n_range += 1
+    for b, bcn in enumerate(bcns):
+        st = pf.getBcnLoc(bcn)
+        if st[0]:
+            res.bcn_rows.append((b,) + tuple(st[2:]))
+    return res

@@ -158,3 +158,25 @@ def test_slam_scenario(ora, flavour):
     for i, b in enumerate(bcns):
         a = _aos([v.reshape(-1) for v in b.arrays()])
         assert _sha(a) == g["final"][f"bcn{i}"]["sha256"]
+
+
+@pytest.mark.parametrize("flavour", list(FLAVOURS))
+def test_cic0_csvslam_replay(ora, flavour):
+    """csvslam.c's replay (12 beacons, bias 0.4, skip to waypoint 4) of the trimmed sampledata/cic/0 trace: the oracle
+    in reference arithmetic reproduces what the compiled reference wrote (tag.csv rows, bcn.csv rows, final PF_SEED)
+    exactly.  The reference has no test of its own for this path."""
+    from slam3d_amd import replay as R
+    with open(os.path.join(GOLDEN, "ref_cic0_slam.json")) as fh:
+        g = json.load(fh)[flavour]
+    d = os.path.join(GOLDEN, "cic0")
+    vio, uwb = R.read_vio_verbose(os.path.join(d, "vio.csv")), R.read_uwb_verbose(os.path.join(d, "uwb.csv"))
+    assert (len(vio), len(uwb)) == (591, 110) and vio[0][0] == 1515283343.999549     # rows before waypoint 4 skipped
+    pf = ora.OracleSlam(100, 1000, rng_mode=FLAVOURS[flavour], seed=g["seed"], acc=ora.ACC_F32)
+    bcns = [pf.addBcn() for _ in range(R.SLAM_NUM_BCNS)]
+    clamp0 = ora.clamp_events()
+    res = R.replay_slam(pf, bcns, vio, uwb)
+    assert ora.clamp_events() == clamp0
+    assert (res.n_vio, res.n_range) == (g["n_vio"], g["n_range"])
+    assert pf.rng.state == g["final_seed"]
+    assert [[float(v) for v in r] for r in res.tag_rows] == g["tag_rows"]
+    assert [[int(r[0])] + [float(v) for v in r[1:]] for r in res.bcn_rows] == g["bcn_rows"]
