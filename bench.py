@@ -210,7 +210,11 @@ def main():
     K, W, n = args.steps, args.warmup, args.n
     bx, truth, rng = scene(K + W + 1)
 
-    if world == 1:
+    force_sharded = os.environ.get("BENCH_FORCE_SHARDED") == "1"      # rehearsal: the sharded host logic on one rank
+    if world == 1 and force_sharded:
+        dist.init_process_group(pg, rank=0, world_size=1, init_method="tcp://127.0.0.1:29533",
+                                **({"device_id": torch.device("cuda", local)} if pg == "nccl" else {}))
+    if world == 1 and not force_sharded:
         pf = pfm.DeviceParticleFilterLoc(n, seed=123456789, stream_id=0, device=local)
     else:
         from slam3d_amd.sharded import ShardedLocFilter

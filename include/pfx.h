@@ -106,19 +106,23 @@ int64_t  pfx_loc_branch_log(pfx_loc* pf, uint8_t* out, int64_t cap, int64_t* tot
  *   pfx_loc_shard_pass1    VIO commit + streaming pass + local tile prefix; 8 local sums land in device memory
  *                          (returns 1 instead if the filter was uninitialised and has just spawned its particles)
  *   all-gather             of pfx_loc_shard_local_ptr (8 doubles) into pfx_loc_shard_all_ptr (rank-major), by the caller
- *   pfx_loc_shard_decide   the reference's ESS / respawn decision on the GLOBAL totals, identical on every rank;
- *                          F[g] = first global offspring index produced by shard g (F[num_shards] = n_global)
- *   pfx_loc_shard_resample offspring of the local ancestors: those with index inside the shard's own range go to
- *                          the new current arrays, the rest to the staging arrays (first those below the range,
- *                          then those above); the caller ships them into the owners' current arrays and sets
- *                          their weights with pfx_loc_shard_fill_w.  Fails if the staging area is too small. */
+ *   pfx_loc_shard_decide_resample  the reference's ESS / respawn decision on the GLOBAL totals, identical on every
+ *                          rank, and right behind it on the stream the resampling of the local ancestors (a no-op on a
+ *                          normalise-only step): offspring with index inside the shard's own range go to the other
+ *                          buffer, the rest to the staging arrays (first those below the range, then those above).
+ *                          Returns without waiting.
+ *   pfx_loc_shard_plan     waits for the decision only (it lands in pinned host memory): branch and F[g] = first
+ *                          global offspring index produced by shard g (F[num_shards] = n_global).  On a resampling
+ *                          step the caller then ships the staged offspring into the owners' current arrays and sets
+ *                          their weights with pfx_loc_shard_fill_w.  Fails if the staging area was too small. */
 int      pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64_t n_global, int64_t self_begin, int64_t stage_capacity);
 int      pfx_loc_shard_pass1(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);
 void*    pfx_loc_shard_local_ptr(pfx_loc* pf);      /* device address: s ss csum ssum wx wy wz 0 */
 void*    pfx_loc_shard_all_ptr(pfx_loc* pf);        /* device address: 16 x 8 doubles */
-int      pfx_loc_shard_decide(pfx_loc* pf, float range, int* out_branch, int64_t* out_F);
-int      pfx_loc_shard_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);
-int      pfx_loc_shard_ptrs(pfx_loc* pf, void* d_stage[4], void* d_current[5]);
+int      pfx_loc_shard_decide_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);
+int      pfx_loc_shard_plan(pfx_loc* pf, int* out_branch, int64_t* out_F);
+int      pfx_loc_shard_ptrs_both(pfx_loc* pf, void* d_stage[4], void* d_buf0[5], void* d_buf1[5]);  /* no synchronisation */
+int      pfx_loc_shard_cur(const pfx_loc* pf);     /* which of the two buffers is current (after pfx_loc_shard_plan) */
 int      pfx_loc_shard_fill_w(pfx_loc* pf, int cur, int64_t begin, int64_t count);
 int      pfx_loc_shard_pose_sums(pfx_loc* pf, double out[6]);   /* local sums of w, wx, wy, wz, w cos, w sin */
 /* particleFilter.c:274-290 on caller-supplied (e.g. all-reduced) pose sums; 1 ok, 0 not initialised */

@@ -75,9 +75,10 @@ def lib() -> C.CDLL:
     sig("pfx_loc_shard_pass1", i, vp, f, f, f, f, f)
     sig("pfx_loc_shard_local_ptr", vp, vp)
     sig("pfx_loc_shard_all_ptr", vp, vp)
-    sig("pfx_loc_shard_decide", i, vp, f, C.POINTER(i), C.POINTER(i64))
-    sig("pfx_loc_shard_resample", i, vp, f, f, f, f, f)
-    sig("pfx_loc_shard_ptrs", i, vp, C.POINTER(vp), C.POINTER(vp))
+    sig("pfx_loc_shard_decide_resample", i, vp, f, f, f, f, f)
+    sig("pfx_loc_shard_plan", i, vp, C.POINTER(i), C.POINTER(i64))
+    sig("pfx_loc_shard_ptrs_both", i, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
+    sig("pfx_loc_shard_cur", i, vp)
     sig("pfx_loc_shard_fill_w", i, vp, i, i64, i64)
     sig("pfx_loc_shard_pose_sums", i, vp, pd_)
     sig("pfx_loc_pose_from_sums", i, vp, pd_, pd_, pf_, pf_, pf_, pf_)

@@ -12,6 +12,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <chrono>
 #include <cmath>
 #include <ctime>
 #include <mutex>
@@ -108,8 +109,9 @@ struct pfx_loc {
     size_t stageCap = 0;
     float* stageSlab = nullptr;     // 4 arrays of stageCap floats
     double* dAll = nullptr;         // kMaxShards * 8 gathered sums
-    ShardPlan* dPlan = nullptr;
-    ShardPlan* hostPlan = nullptr;  // pinned
+    ShardPlan* hostPlan = nullptr;  // pinned, device-mapped: the decision kernel writes it, the host polls it
+    ShardPlan* dPlanMapped = nullptr;   // device address of hostPlan
+    int shardCur = 0;               // host-side track of the current buffer (sharded filters only)
     // profiling
     std::vector<ProfRec> prof;
     size_t profUsed = 0;
@@ -196,6 +198,7 @@ int launch_resample(pfx_loc* pf, float bx, float by, float bz, float range, floa
     const dim3 grid(pf->numTiles), block(kThreads);
     StagePtrs st{};
     for (int k = 0; k < 4; ++k) st.a[k] = pf->stageSlab ? pf->stageSlab + (size_t)k * pf->stageCap : nullptr;
+    st.cap = pf->stageSlab ? (long long)pf->stageCap : 0;
     if (pf->recordAnc)
         hipExtLaunchKernelGGL((k_loc_resample<true>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase, pf->tileIncl,
                            pf->anc, pf->numTiles, pf->n, st, key_of(pf), bx, by, bz, range, stdRange);
@@ -261,7 +264,6 @@ void free_device(pfx_loc* pf)
     if (pf->hostCtl) hipHostFree(pf->hostCtl);
     if (pf->stageSlab) hipFree(pf->stageSlab);
     if (pf->dAll) hipFree(pf->dAll);
-    if (pf->dPlan) hipFree(pf->dPlan);
     if (pf->hostPlan) hipHostFree(pf->hostPlan);
     for (auto& r : pf->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     pf->prof.clear();
@@ -613,8 +615,10 @@ extern "C" int pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64
     pf->rank = rank; pf->numShards = num_shards; pf->nGlobal = n_global; pf->selfBegin = self_begin;
     if (!pf->dAll) {
         PF_HIP_OK(hipMalloc((void**)&pf->dAll, kMaxShards * 8 * sizeof(double)));
-        PF_HIP_OK(hipMalloc((void**)&pf->dPlan, sizeof(ShardPlan)));
-        PF_HIP_OK(hipHostMalloc((void**)&pf->hostPlan, sizeof(ShardPlan), hipHostMallocDefault));
+        PF_HIP_OK(hipHostMalloc((void**)&pf->hostPlan, sizeof(ShardPlan), hipHostMallocMapped));
+        memset(pf->hostPlan, 0, sizeof(ShardPlan));
+        pf->hostPlan->seq = ~0ull;
+        PF_HIP_OK(hipHostGetDevicePointer((void**)&pf->dPlanMapped, pf->hostPlan, 0));
     }
     if (stage_capacity > 0 && (size_t)stage_capacity != pf->stageCap) {
         if (pf->stageSlab) { PF_HIP_OK(hipStreamSynchronize(pf->stream)); hipFree(pf->stageSlab); pf->stageSlab = nullptr; }
@@ -636,6 +640,7 @@ extern "C" int pfx_loc_shard_pass1(pfx_loc* pf, float bx, float by, float bz, fl
     if (!pf->initialized) {
         if (launch_spawn(pf, bx, by, bz, range, stdRange)) return -1;
         pf->initialized = true;
+        pf->shardCur = 0;
         return 1;
     }
     if (launch_stream(pf, !is_zero_motion(d), true, motion_of(d), gate_of(bx, by, bz, range, stdRange))) return -1;
@@ -646,43 +651,69 @@ extern "C" int pfx_loc_shard_pass1(pfx_loc* pf, float bx, float by, float bz, fl
 extern "C" void* pfx_loc_shard_local_ptr(pfx_loc* pf) { return (void*)pf->ctl->local; }   // device address, 8 doubles
 extern "C" void* pfx_loc_shard_all_ptr(pfx_loc* pf) { return (void*)pf->dAll; }           // device, kMaxShards*8 doubles
 
-// out_F: num_shards + 1 global offspring boundaries (meaningful when *out_branch == 1)
-extern "C" int pfx_loc_shard_decide(pfx_loc* pf, float range, int* out_branch, int64_t* out_F)
+// The global decision and, in the same breath, the local resampling it may call for -- nothing waits for the host:
+// k_loc_shard_decide writes the plan into pinned host memory (sequence number last) and k_loc_resample follows on
+// the stream, exiting at once on a normalise-only step.
+extern "C" int pfx_loc_shard_decide_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
 {
     clear_error();
-    if (!pf->dAll) { set_error("pfx_loc_shard_decide: call pfx_loc_shard_config first"); return -2; }
+    if (!pf->dAll) { set_error("pfx_loc_shard_decide_resample: call pfx_loc_shard_config first"); return -2; }
     DeviceGuard g(pf->device);
     {
         ProfScope ps(pf, PFX_K_DECIDE);
-        hipExtLaunchKernelGGL(k_loc_shard_decide, dim3(1), dim3(64), 0, pf->stream, ps.a(), ps.b(), 0, pf->ctl, pf->dAll, pf->numShards, pf->rank,
-                           pf->nGlobal, pf->selfBegin, pf->selfBegin + pf->n, range, key_of(pf), pf->force, pf->branchLog,
-                           pf->dPlan);
+        hipExtLaunchKernelGGL(k_loc_shard_decide, dim3(1), dim3(64), 0, pf->stream, ps.a(), ps.b(), 0, pf->ctl, pf->dAll, pf->numShards,
+                              pf->rank, pf->nGlobal, pf->selfBegin, pf->selfBegin + pf->n, range, key_of(pf), pf->force, pf->branchLog,
+                              pf->dPlanMapped, (unsigned long long)pf->epoch);
         if (check_launch("k_loc_shard_decide")) return -1;
     }
-    PF_HIP_OK(hipMemcpyAsync(pf->hostPlan, pf->dPlan, sizeof(ShardPlan), hipMemcpyDeviceToHost, pf->stream));
-    PF_HIP_OK(hipStreamSynchronize(pf->stream));
-    *out_branch = pf->hostPlan->branch;
-    for (int k = 0; k <= pf->numShards; ++k) out_F[k] = pf->hostPlan->F[k];
-    return 0;
+    return launch_resample(pf, bx, by, bz, range, stdRange);
 }
 
-extern "C" int pfx_loc_shard_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+// Wait for the plan of the current deposit (polls the pinned copy; falls back to a stream synchronisation).
+// out_F: num_shards + 1 global offspring boundaries (meaningful when *out_branch == 1).  Fails if the offspring
+// that belong to other shards did not fit the staging area (the kernel dropped the excess).
+extern "C" int pfx_loc_shard_plan(pfx_loc* pf, int* out_branch, int64_t* out_F)
 {
     clear_error();
+    if (!pf->hostPlan) { set_error("pfx_loc_shard_plan: call pfx_loc_shard_config first"); return -2; }
     DeviceGuard g(pf->device);
-    if (pf->hostPlan && pf->hostPlan->branch == 1) {
-        const long long ob = pf->hostPlan->F[pf->rank], oe = pf->hostPlan->F[pf->rank + 1];
+    const unsigned long long want = (unsigned long long)pf->epoch;
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (__atomic_load_n(&pf->hostPlan->seq, __ATOMIC_ACQUIRE) != want) {
+        if ((++spins & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) {
+            PF_HIP_OK(hipStreamSynchronize(pf->stream));        // the kernel has run: its stores are visible now
+            if (pf->hostPlan->seq != want) { set_error("pfx_loc_shard_plan: no plan for deposit %llu", want); return -1; }
+        }
+    }
+    const ShardPlan* p = pf->hostPlan;
+    *out_branch = p->branch;
+    for (int k = 0; k <= pf->numShards; ++k) out_F[k] = p->F[k];
+    if (p->branch == 1) {
+        const long long ob = p->F[pf->rank], oe = p->F[pf->rank + 1];
         const long long sb = pf->selfBegin, se = pf->selfBegin + pf->n;
         const long long below = sb > ob ? (sb < oe ? sb : oe) - ob : 0;
         const long long above = oe > se ? oe - (se > ob ? se : ob) : 0;
         if ((size_t)(below + above) > pf->stageCap) {
-            set_error("pfx_loc_shard_resample: %lld offspring belong to other shards but the staging area holds %zu "
+            set_error("pfx_loc_shard_plan: %lld offspring belong to other shards but the staging area holds %zu "
                       "(shard imbalance beyond the configured slack)", below + above, pf->stageCap);
             return -3;
         }
+        pf->shardCur ^= 1;
     }
-    return launch_resample(pf, bx, by, bz, range, stdRange);
+    return 0;
 }
+
+// device pointers: the staging arrays (x,y,z,theta) and BOTH particle buffers (w,x,y,z,theta); no synchronisation.
+// pfx_loc_shard_cur tells which buffer is current after the last pfx_loc_shard_plan (tracked on the host).
+extern "C" int pfx_loc_shard_ptrs_both(pfx_loc* pf, void* stage[4], void* buf0[5], void* buf1[5])
+{
+    clear_error();
+    for (int k = 0; k < 4; ++k) stage[k] = pf->stageSlab ? (void*)(pf->stageSlab + (size_t)k * pf->stageCap) : nullptr;
+    for (int k = 0; k < 5; ++k) { buf0[k] = pf->bufs.a[0][k]; buf1[k] = pf->bufs.a[1][k]; }
+    return 0;
+}
+extern "C" int pfx_loc_shard_cur(const pfx_loc* pf) { return pf->shardCur; }
 
 // device pointers: the staging arrays (x,y,z,theta) and the CURRENT particle arrays (w,x,y,z,theta).  After a
 // resampling decision "current" is the buffer the offspring are written to.  Uses the host copy of the plan.

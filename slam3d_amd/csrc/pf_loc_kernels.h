@@ -57,6 +57,7 @@ struct ShardPlan {
     float htheta, wscale;
     double S, rStart, rStep;
     long long F[kMaxShards + 1];    // F[g] = first global offspring index produced by shard g; F[G] = nGlobal
+    unsigned long long seq;         // written last: the deposit (epoch) this plan belongs to
 };
 
 constexpr int kBranchLogSize = 65536;
@@ -289,8 +290,9 @@ __global__ __launch_bounds__(64) void k_loc_decide(LocCtl* __restrict__ ctl, con
 // this shard's span of the global CDF and the first offspring index of every shard.  One thread.
 __global__ void k_loc_shard_decide(LocCtl* __restrict__ ctl, const double* __restrict__ all, int numShards, int rank,
                                    long long nGlobal, long long selfBegin, long long selfEnd, float range, RngKey key,
-                                   int force, unsigned char* __restrict__ branchLog, ShardPlan* __restrict__ plan)
-{
+                                   int force, unsigned char* __restrict__ branchLog, ShardPlan* plan,
+                                   unsigned long long seq)
+{   // `plan` lives in pinned host memory: the host polls plan->seq instead of synchronising the stream
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double tot[7] = { 0, 0, 0, 0, 0, 0, 0 };
     double base[kMaxShards + 1];
@@ -317,6 +319,8 @@ __global__ void k_loc_shard_decide(LocCtl* __restrict__ ctl, const double* __res
     ctl->shardBase = base[rank]; ctl->shardEnd = base[rank + 1];
     ctl->outBegin = plan->F[rank]; ctl->outEnd = plan->F[rank + 1];
     ctl->selfBegin = selfBegin; ctl->selfEnd = selfEnd; ctl->nGlobal = nGlobal;
+    __threadfence_system();
+    __hip_atomic_store(&plan->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void k_fill(float* __restrict__ p, float v, long long count)
@@ -358,7 +362,7 @@ __device__ __forceinline__ long long first_offspring_at(double b, double rStart,
 // ------------------------------------------------------------------ resample
 // Staging arrays for offspring whose place is on another shard (sharded filters only; null otherwise):
 // x,y,z,theta of the offspring below this shard's own index range first, then those above it.
-struct StagePtrs { float* a[4]; };
+struct StagePtrs { float* a[4]; long long cap; };
 
 // Structure (measured, MI355X, N = 16 M): a version that gathered the ancestors from global memory with one dword
 // load per lane and stored one dword per lane and array ran at 0.14 ms whatever was left of its arithmetic; the
@@ -498,6 +502,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
                         if (RECORD) da[k] = (int)(tbase + jj[m]);
                     } else {
                         const long long p = (k < kSelfB ? lo : hi) + k;
+                        if (p >= stage.cap) continue;   // shard imbalance beyond the staging area: the host reports it
                         stage.a[0][p] = ox[m]; stage.a[1][p] = oy[m]; stage.a[2][p] = oz[m]; stage.a[3][p] = ot[m];
                     }
                 }

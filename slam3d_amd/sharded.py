@@ -96,8 +96,10 @@ class GpuShard:
         dev = f"cuda:{self.device}"
         self._local = torch.as_tensor(_DevMem(self._L.pfx_loc_shard_local_ptr(self._h), 8, "<f8"), device=dev)
         self._all = torch.as_tensor(_DevMem(self._L.pfx_loc_shard_all_ptr(self._h), MAX_SHARDS * 8, "<f8"), device=dev)
-        self._cur = 0
-        self._refresh_views()
+        st, b0, b1 = (C.c_void_p * 4)(), (C.c_void_p * 5)(), (C.c_void_p * 5)()
+        self._lib.check(self._L.pfx_loc_shard_ptrs_both(self._h, st, b0, b1), "pfx_loc_shard_ptrs_both")
+        self._stage = [torch.as_tensor(_DevMem(p, self.stage_capacity, "<f4"), device=dev) if p else None for p in st]
+        self._bufs = [[torch.as_tensor(_DevMem(p, self.n, "<f4"), device=dev) for p in b] for b in (b0, b1)]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -110,13 +112,10 @@ class GpuShard:
         except Exception:
             pass
 
-    def _refresh_views(self):
-        torch = self._torch
-        st, cur = (C.c_void_p * 4)(), (C.c_void_p * 5)()
-        self._lib.check(self._L.pfx_loc_shard_ptrs(self._h, st, cur), "pfx_loc_shard_ptrs")
-        dev = f"cuda:{self.device}"
-        self._stage = [torch.as_tensor(_DevMem(p, self.stage_capacity, "<f4"), device=dev) if p else None for p in st]
-        self._curr = [torch.as_tensor(_DevMem(p, self.n, "<f4"), device=dev) for p in cur]
+    @property
+    def _curr(self):
+        """w, x, y, z, theta views of the current buffer (the library tracks which one on the host: no sync)"""
+        return self._bufs[self._L.pfx_loc_shard_cur(self._h)]
 
     # -- VIO bookkeeping and control are the library's
     def deposit_vio(self, t, x, y, z, dist):
@@ -135,15 +134,14 @@ class GpuShard:
     def all_sums(self):
         return self._all[: self.world * 8]
 
-    def decide(self, rng) -> Tuple[int, List[int]]:
+    def decide_resample(self, bx, by, bz, rng, std) -> Tuple[int, List[int]]:
+        """global decision + local resampling enqueued back to back; only the decision is waited for (the resample
+        kernel keeps running while the host plans the exchange)"""
+        self._lib.check(self._L.pfx_loc_shard_decide_resample(self._h, bx, by, bz, rng, std), "pfx_loc_shard_decide_resample")
         br = C.c_int()
         F = (C.c_int64 * (MAX_SHARDS + 1))()
-        self._lib.check(self._L.pfx_loc_shard_decide(self._h, rng, C.byref(br), F), "pfx_loc_shard_decide")
+        self._lib.check(self._L.pfx_loc_shard_plan(self._h, C.byref(br), F), "pfx_loc_shard_plan")
         return br.value, [int(F[k]) for k in range(self.world + 1)]
-
-    def resample(self, bx, by, bz, rng, std):
-        self._lib.check(self._L.pfx_loc_shard_resample(self._h, bx, by, bz, rng, std), "pfx_loc_shard_resample")
-        self._refresh_views()       # the offspring buffer is now the current one
 
     def stage_views(self, off, count):
         return [s[off: off + count] for s in self._stage]
@@ -267,16 +265,12 @@ class ShardedLocFilter:
             self.initialized = True             # first range: every shard spawned its own particles
             return
         self._all_gather(sh.all_sums(), sh.local_sums())
-        branch, F = sh.decide(range)
+        branch, F = sh.decide_resample(bx, by, bz, range, stdRange)
         self.last_branch, self.last_F = branch, F
         if not branch:
             return
         sends, recvs, _below = exchange_plan(F, self.T, self.rank)
         staged = sum(c for _, _, c in sends)
-        if staged > self.stage_capacity:
-            raise RuntimeError(f"rank {self.rank}: {staged} offspring belong to other shards, staging holds "
-                               f"{self.stage_capacity} (raise stage_slack)")
-        sh.resample(bx, by, bz, range, stdRange)
         self._p2p([(p, sh.stage_views(off, cnt)) for p, off, cnt in sends],
                   [(p, sh.current_views(off, cnt)) for p, off, cnt in recvs])
         for _p, off, cnt in recvs:

@@ -125,6 +125,13 @@ class OracleShard:
         self.F = F
         return self.branch, F
 
+    def decide_resample(self, bx, by, bz, rng, std):
+        """the GpuShard interface: decision and (if it says so) the local resampling in one call"""
+        branch, F = self.decide(rng)
+        if branch:
+            self.resample(bx, by, bz, rng, std)
+        return branch, F
+
     def resample(self, bx, by, bz, rng, std):
         w, x, y, z, th = self.pf.arrays()
         cdf = self.base[self.rank] + np.cumsum(w.astype(np.float64))
