@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
 {
     // idx0: global index of local particle 0 (0 unless the filter is one shard of a larger one); the
     // Philox counter uses the global index, so the noise does not depend on how the filter is sharded
-    __shared__ double red[4 * 7];
+    __shared__ double red[7 * kThreads];
     const int cur = ctl->cur;
     const float wscale = ctl->wscale;
     float* __restrict__ pw = bufs.a[cur][0];
@@ -143,12 +143,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
         *reinterpret_cast<float4*>(pt + base) = make_float4(th[0], th[1], th[2], th[3]);
     }
 
-    block_sum<7>(acc, red);
-    if (threadIdx.x == 0) {
-        double* o = tileSums + (size_t)blockIdx.x * kSumsPerTile;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) o[k] = acc[k];
-    }
+    block_sum_store<7>(acc, red, tileSums + (size_t)blockIdx.x * kSumsPerTile);
 }
 
 // ------------------------------------------------------------------ two-level prefix, level 1
@@ -520,7 +515,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_pose_tiles(LocBufs bufs, const
                                                             double* __restrict__ rsPart, long long n)
 {
     if (ctl->branch != 1 || ctl->rsValid) return;
-    __shared__ double red[4 * 6];
+    __shared__ double red[6 * kThreads];
     const int cur = ctl->cur;
     const float wscale = ctl->wscale;
     const long long base = (long long)blockIdx.x * kTile + (long long)threadIdx.x * kPerThread;
@@ -540,12 +535,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_pose_tiles(LocBufs bufs, const
         acc[0] += wi * x[k]; acc[1] += wi * y[k]; acc[2] += wi * z[k];
         acc[3] += wi * cs; acc[4] += wi * sn; acc[5] += wi;
     }
-    block_sum<6>(acc, red);
-    if (threadIdx.x == 0) {
-        double* o = rsPart + (size_t)blockIdx.x * kRsPerTile;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o[k] = acc[k];
-    }
+    block_sum_store<6>(acc, red, rsPart + (size_t)blockIdx.x * kRsPerTile);
 }
 
 // ------------------------------------------------------------------ initial spawn (pfInit.c:20-25)
@@ -553,7 +543,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_spawn(LocBufs bufs, LocCtl* __
                                                        long long n, long long idx0, RngKey key, float bx, float by, float bz,
                                                        float range, float stdRange)
 {
-    __shared__ double red[4 * 6];
+    __shared__ double red[6 * kThreads];
     const int cur = ctl->cur;
     float* __restrict__ pw = bufs.a[cur][0];
     float* __restrict__ px = bufs.a[cur][1];
@@ -576,12 +566,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_spawn(LocBufs bufs, LocCtl* __
             pw[i] = 0.0f; px[i] = 0.0f; py[i] = 0.0f; pz[i] = 0.0f; pt[i] = 0.0f;
         }
     }
-    block_sum<6>(acc, red);
-    if (threadIdx.x == 0) {
-        double* o = rsPart + (size_t)blockIdx.x * kRsPerTile;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o[k] = acc[k];
-    }
+    block_sum_store<6>(acc, red, rsPart + (size_t)blockIdx.x * kRsPerTile);
 }
 
 // ------------------------------------------------------------------ small control kernels

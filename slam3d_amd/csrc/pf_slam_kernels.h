@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kThreads) void k_slam_rows(SlamPtrs P, SlamDims D, 
 // particleFilter.c:302-333: sums of w, wx, wy, wz, w cos, w sin over the tag particles of each filter
 __global__ __launch_bounds__(kThreads) void k_slam_tag_pose(SlamPtrs P, SlamDims D, double* __restrict__ tagPose)
 {
-    __shared__ double red[4 * 6];
+    __shared__ double red[6 * kThreads];
     const int f = blockIdx.x, n = D.nTag, j0 = threadIdx.x * 4;
     const float* const src[5] = { P.tag[0], P.tag[1], P.tag[2], P.tag[3], P.tag[4] };
     Row4 r;
@@ -358,11 +358,7 @@ __global__ __launch_bounds__(kThreads) void k_slam_tag_pose(SlamPtrs P, SlamDims
         const float w = r.w[k];
         acc[0] += w; acc[1] += w * r.x[k]; acc[2] += w * r.y[k]; acc[3] += w * r.z[k]; acc[4] += w * cs; acc[5] += w * sn;
     }
-    block_sum<6>(acc, red);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) tagPose[(size_t)f * 6 + k] = acc[k];
-    }
+    block_sum_store<6>(acc, red, tagPose + (size_t)f * 6);
 }
 
 // particleFilter.c:353-378, inner loop: per tag particle i the weighted sums of its beacon row, folded into the
