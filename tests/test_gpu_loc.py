@@ -404,3 +404,48 @@ def test_config2_range_only_1m(pfm, test1):
     assert abs(float(x) + 0.6065) < 0.0235 and abs(float(y) - 3.2254) < 0.0115 and abs(float(z) - 1.9666) < 0.0465
     w = g.download()[0]
     assert np.isfinite(w).all() and w.min() >= 0.0
+
+
+# ------------------------------------------------------------------ degenerate weights (edge semantics)
+@pytest.mark.parametrize("n", [5000, 3 * 1024 + 17])
+def test_all_weights_zero_far_range_normalises_to_nan(pfm, ora, n):
+    """All weights underflowed to 0 and range >= 4 m: ess = 0/0 is NaN, both tests of pfResample.c:58 are false, the
+    step normalises with m = N/0 = inf and every weight becomes 0 * inf = NaN -- on the GPU (deferred factor) as in
+    the reference arithmetic."""
+    g, o = _pair(pfm, ora, n)
+    p = _synth.loc_particles(n, 41, "mixed")
+    p[:, 0] = 0.0
+    _load(g, o, p, epoch=5)
+    g.resample(1.0, 2.0, 0.5, 6.0, 0.1)
+    o.resample(1.0, 2.0, 0.5, 6.0, 0.1)
+    gs, os_ = g.last_stats(), o.last_stats()
+    assert int(gs["branch"]) == int(os_["branch"]) == 0
+    assert np.isnan(gs["ess"]) and np.isnan(os_["ess"]) and np.isinf(gs["m"]) and np.isinf(os_["m"])
+    assert np.isnan(g.download()[0]).all() and np.isnan(o.arrays()[0]).all()
+
+
+@pytest.mark.parametrize("n", [5000, 3 * 1024 + 17])
+def test_all_weights_zero_near_range_respawns(pfm, ora, n):
+    """All weights 0 and range < 4 m: the respawn test fires (mean weight 0 < 0.4), the step resamples with rStep = 0;
+    every u_i = 0 fails `u < cdf[j]` for all j, so every offspring descends from the LAST particle (the reference walks
+    to the end of its CDF; the clamp keeps it there), and the first 5 % are respawned on the range shell."""
+    g, o = _pair(pfm, ora, n)
+    p = _synth.loc_particles(n, 42, "mixed")
+    p[:, 0] = 0.0
+    _load(g, o, p, epoch=6)
+    g.record_ancestors(True)
+    g.resample(1.0, 2.0, 0.5, 2.0, 0.1)
+    o.resample(1.0, 2.0, 0.5, 2.0, 0.1)
+    gs, os_ = g.last_stats(), o.last_stats()
+    assert int(gs["branch"]) == int(os_["branch"]) == 1
+    ns = int(os_["numSpawn"])
+    assert int(gs["numSpawn"]) == ns == int(np.round(np.float32(n) * np.float32(0.05)))
+    assert np.all(g.last_ancestors()[ns:] == n - 1) and np.all(o.last_ancestors()[ns:] == n - 1)
+    got, exp = g.download(), o.arrays()
+    assert np.all(got[0] == 1.0)
+    r = np.sqrt((got[1][:ns] - 1.0) ** 2 + (got[2][:ns] - 2.0) ** 2 + (got[3][:ns] - 0.5) ** 2)
+    assert np.all(np.abs(r - 2.0) <= 0.3 + 1e-5)
+    for k in range(1, 4):
+        # htheta is NaN here (ess NaN): positions are finite, the jittered headings are NaN on both sides
+        assert np.abs(got[k] - exp[k]).max() <= 5e-6
+    assert np.isnan(got[4][ns:]).all() and np.isnan(exp[4][ns:]).all()

@@ -44,6 +44,8 @@ __global__ __launch_bounds__(kThreads) void k_var(LocBufs bufs, const LocCtl* __
 }
 
 template <typename F> float timeit(F f, int reps){ hipEvent_t a,b; hipEventCreate(&a); hipEventCreate(&b); f(); f(); hipDeviceSynchronize(); hipEventRecord(a); for(int i=0;i<reps;++i) f(); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms,a,b); return ms/reps; }
+__global__ void k_flush(float4* p, long long n4){ long long i=(long long)blockIdx.x*256+threadIdx.x; if(i<n4){ float4 v=p[i]; v.x+=1.f; p[i]=v; } }
+template <typename F, typename G> float timeit_cold(F f, G flush, int reps){ hipEvent_t a,b; hipEventCreate(&a); hipEventCreate(&b); float tot=0; for(int i=0;i<reps+2;++i){ flush(); hipEventRecord(a); f(); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms,a,b); if(i>=2) tot+=ms; } return tot/reps; }
 int main(){
     const long long n = 16000000; const int tiles = (int)(n/1024);
     float* slab; hipMalloc(&slab, n*10*4);
@@ -56,6 +58,13 @@ int main(){
     printf("stream<0,1>: %.4f ms\n", timeit([&]{ hipLaunchKernelGGL((k_loc_stream<false,true>), dim3(tiles), dim3(256),0,0,b,ctl,ts,n,0ll,key,mo,ga); },50));
     printf("stream<0,0>: %.4f ms\n", timeit([&]{ hipLaunchKernelGGL((k_loc_stream<false,false>), dim3(tiles), dim3(256),0,0,b,ctl,ts,n,0ll,key,mo,ga); },50));
     printf("stream<1,1>: %.4f ms\n", timeit([&]{ hipLaunchKernelGGL((k_loc_stream<true,true>), dim3(tiles), dim3(256),0,0,b,ctl,ts,n,0ll,key,mo,ga); },50));
+    float4* fl; const long long n4 = 40000000; hipMalloc(&fl, n4*16);    // 640 MB read+written between timed launches
+    auto flush=[&]{ hipLaunchKernelGGL(k_flush, dim3((unsigned)((n4+255)/256)), dim3(256),0,0,fl,n4); };
+    printf("cold (640 MB of other traffic before each launch):\n");
+    printf("  stream<0,1>: %.4f ms\n", timeit_cold([&]{ hipLaunchKernelGGL((k_loc_stream<false,true>), dim3(tiles), dim3(256),0,0,b,ctl,ts,n,0ll,key,mo,ga); },flush,20));
+    printf("  stream<1,1>: %.4f ms\n", timeit_cold([&]{ hipLaunchKernelGGL((k_loc_stream<true,true>), dim3(tiles), dim3(256),0,0,b,ctl,ts,n,0ll,key,mo,ga); },flush,20));
+    printf("  k_var<4> (no block sum): %.4f ms\n", timeit_cold([&]{ hipLaunchKernelGGL((k_var<4>), dim3(tiles), dim3(256),0,0,b,ctl,ts,n,ga); },flush,20));
+    printf("  k_var<0> (shuffle sum): %.4f ms\n", timeit_cold([&]{ hipLaunchKernelGGL((k_var<0>), dim3(tiles), dim3(256),0,0,b,ctl,ts,n,ga); },flush,20));
 #define VAR(M) printf("k_var<%d>: %.4f ms\n", M, timeit([&]{ hipLaunchKernelGGL((k_var<M>), dim3(tiles), dim3(256),0,0,b,ctl,ts,n,ga); },50));
     VAR(0) VAR(1) VAR(2) VAR(3) VAR(4) VAR(5) VAR(6) VAR(7) VAR(16) VAR(24) VAR(19)
     return 0;
