@@ -90,7 +90,10 @@ struct pfx_slam {
     float* tagSlab = nullptr;
     float* bcnSlab = nullptr;
     float* rowSum = nullptr;        // F * nTag
+    float* rowScale = nullptr;      // F * B * nTag: pending normalisation factor of every beacon row
+    int* rowFlag = nullptr;         // F * nTag: what k_slam_gate_rows did to the measured beacon's rows
     int* tagBranch = nullptr;       // F
+    int* forcedList = nullptr;      // F + 1: filters whose tag particles the current deposit resampled; [F] = their number
     double* tagPose = nullptr;      // F * 6
     double* bcnPose = nullptr;      // F * 6
     float* rowTerms = nullptr;      // F * nTag * 6
@@ -131,7 +134,10 @@ void free_slam(pfx_slam* pf)
     if (pf->tagSlab) hipFree(pf->tagSlab);
     if (pf->bcnSlab) hipFree(pf->bcnSlab);
     if (pf->rowSum) hipFree(pf->rowSum);
+    if (pf->rowScale) hipFree(pf->rowScale);
+    if (pf->rowFlag) hipFree(pf->rowFlag);
     if (pf->tagBranch) hipFree(pf->tagBranch);
+    if (pf->forcedList) hipFree(pf->forcedList);
     if (pf->tagPose) hipFree(pf->tagPose);
     if (pf->bcnPose) hipFree(pf->bcnPose);
     if (pf->rowTerms) hipFree(pf->rowTerms);
@@ -159,8 +165,14 @@ int alloc_slam(pfx_slam* pf)
     PF_HIP_OK(hipMemsetAsync(pf->bcnSlab, 0, bcnN * 5 * sizeof(float), pf->stream));
     for (int k = 0; k < 5; ++k) { pf->P.tag[k] = pf->tagSlab + k * tagN; pf->P.bcn[k] = pf->bcnSlab + k * bcnN; }
     PF_HIP_OK(hipMalloc((void**)&pf->rowSum, F * D.nTag * sizeof(float)));
+    PF_HIP_OK(hipMalloc((void**)&pf->rowScale, F * D.maxBcns * D.nTag * sizeof(float)));
+    PF_HIP_OK(hipMemsetD32Async((hipDeviceptr_t)pf->rowScale, 0x3f800000, F * D.maxBcns * D.nTag, pf->stream));    // 1.0f
+    PF_HIP_OK(hipMalloc((void**)&pf->rowFlag, F * D.nTag * sizeof(int)));
+    PF_HIP_OK(hipMemsetAsync(pf->rowFlag, 0, F * D.nTag * sizeof(int), pf->stream));
     PF_HIP_OK(hipMalloc((void**)&pf->tagBranch, F * sizeof(int)));
     PF_HIP_OK(hipMemsetAsync(pf->tagBranch, 0, F * sizeof(int), pf->stream));
+    PF_HIP_OK(hipMalloc((void**)&pf->forcedList, (F + 1) * sizeof(int)));
+    PF_HIP_OK(hipMemsetAsync(pf->forcedList, 0, (F + 1) * sizeof(int), pf->stream));
     PF_HIP_OK(hipMalloc((void**)&pf->tagPose, F * 6 * sizeof(double)));
     PF_HIP_OK(hipMalloc((void**)&pf->bcnPose, F * 6 * sizeof(double)));
     PF_HIP_OK(hipMalloc((void**)&pf->rowTerms, F * D.nTag * 6 * sizeof(float)));
@@ -197,7 +209,7 @@ int slam_step(pfx_slam* pf, const StepReq* req, int nReq)
         for (int f = 0; f < F; ++f) steps[f].mode = 0;
     }
     bmo = single ? pf->hBcnMo[0] : pf->hBcnMo[slot];
-    bool anyMoving = false, anyUpdate = false;
+    bool anyMoving = false, anyUpdate = false, anySpawn = false;
     for (int q = 0; q < nReq; ++q) {
         const StepReq& r = req[q];
         if (r.f < 0 || r.f >= F) { set_error("slam deposit: filter %d not in [0,%d)", r.f, F); return -2; }
@@ -223,7 +235,7 @@ int slam_step(pfx_slam* pf, const StepReq* req, int nReq)
         s.range = r.range; s.stdRange = r.stdRange;
         s.thresh = 3 * r.stdRange;                          // pfMeasurement.c:146
         s.minWeight = (r.range < 3.0f) ? 0.1f : 0.5f;       // pfMeasurement.c:22
-        if (s.mode == 1) anyUpdate = true;
+        if (s.mode == 1) anyUpdate = true; else anySpawn = true;
         fh.bcnInit[r.target] = true;                        // particleFilter.c:208
     }
     const SlamStep* dMany = nullptr;
@@ -245,14 +257,23 @@ int slam_step(pfx_slam* pf, const StepReq* req, int nReq)
         pf->ringUsed[slot] = true;
     }
     if (anyUpdate) {
-        hipLaunchKernelGGL(k_slam_gate, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo, pf->rowSum);
-        if (check_launch("k_slam_gate")) return -1;
+        hipLaunchKernelGGL(k_slam_gate_rows, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo, pf->rowSum,
+                           pf->rowScale, pf->rowFlag, pf->forcedList + F);
+        if (check_launch("k_slam_gate_rows")) return -1;
     }
-    hipLaunchKernelGGL(k_slam_tag, dim3(F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->rowSum, pf->tagBranch);
+    hipLaunchKernelGGL(k_slam_tag, dim3(F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->rowSum, pf->tagBranch, pf->forcedList,
+                       pf->forcedList + F);
     if (check_launch("k_slam_tag")) return -1;
-    hipLaunchKernelGGL(k_slam_rows, dim3(D.nTag, D.maxBcns, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo,
-                       pf->tagBranch);
-    if (check_launch("k_slam_rows")) return -1;
+    if (anySpawn || anyMoving) {
+        hipLaunchKernelGGL(k_slam_rows, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo, pf->rowScale,
+                           pf->rowFlag);
+        if (check_launch("k_slam_rows")) return -1;
+    }
+    if (anyUpdate) {
+        hipLaunchKernelGGL(k_slam_rows_forced, dim3(D.nTag, F < 64 ? F : 64), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany,
+                           pf->dBcnMo, pf->rowScale, pf->rowFlag, pf->forcedList, pf->forcedList + F);
+        if (check_launch("k_slam_rows_forced")) return -1;
+    }
     pf->deposits++;
     return 0;
 }
@@ -299,7 +320,7 @@ int bcn_pose_sums(pfx_slam* pf, const int* slots)
     const int F = D.numFilters;
     PF_HIP_OK(hipMemcpyAsync(pf->slotOf, slots, (size_t)F * sizeof(int), hipMemcpyHostToDevice, pf->stream));
     PF_HIP_OK(hipStreamSynchronize(pf->stream));        // `slots` may be pageable and short-lived
-    hipLaunchKernelGGL(k_slam_bcn_rows_pose, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, pf->slotOf, pf->rowTerms);
+    hipLaunchKernelGGL(k_slam_bcn_rows_pose, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, pf->slotOf, pf->rowScale, pf->rowTerms);
     if (check_launch("k_slam_bcn_rows_pose")) return -1;
     hipLaunchKernelGGL(k_slam_bcn_pose, dim3(F), dim3(kThreads), 0, pf->stream, D, pf->slotOf, pf->rowTerms, pf->bcnPose);
     if (check_launch("k_slam_bcn_pose")) return -1;
@@ -580,7 +601,16 @@ extern "C" int pfx_slam_download_bcn(pfx_slam* pf, int f, int slot, float* w, fl
     if (check_slot(pf, f, slot, "pfx_slam_download_bcn")) return -2;
     DeviceGuard g(pf->device);
     float* host[5] = { w, x, y, z, theta };
-    return copy_rows(pf, pf->P.bcn, slam_row_base(pf->D, f, slot, 0), pf->D.nTag, pf->D.nBcn, pf->D.rowStride, host, true);
+    if (copy_rows(pf, pf->P.bcn, slam_row_base(pf->D, f, slot, 0), pf->D.nTag, pf->D.nBcn, pf->D.rowStride, host, true)) return -1;
+    if (w) {    // pending w *= N/s of the rows that were normalised last (pfResample.c:195-199)
+        std::vector<float> sc((size_t)pf->D.nTag);
+        PF_HIP_OK(hipMemcpy(sc.data(), pf->rowScale + ((size_t)f * pf->D.maxBcns + slot) * pf->D.nTag, sc.size() * sizeof(float),
+                            hipMemcpyDeviceToHost));
+        for (int i = 0; i < pf->D.nTag; ++i)
+            if (sc[(size_t)i] != 1.0f)
+                for (int j = 0; j < pf->D.nBcn; ++j) w[(size_t)i * pf->D.nBcn + j] *= sc[(size_t)i];
+    }
+    return 0;
 }
 
 extern "C" int pfx_slam_upload_bcn(pfx_slam* pf, int f, int slot, const float* w, const float* x, const float* y, const float* z,
@@ -591,6 +621,8 @@ extern "C" int pfx_slam_upload_bcn(pfx_slam* pf, int f, int slot, const float* w
     DeviceGuard g(pf->device);
     float* host[5] = { (float*)w, (float*)x, (float*)y, (float*)z, (float*)theta };
     if (copy_rows(pf, pf->P.bcn, slam_row_base(pf->D, f, slot, 0), pf->D.nTag, pf->D.nBcn, pf->D.rowStride, host, false)) return -1;
+    if (w) PF_HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(pf->rowScale + ((size_t)f * pf->D.maxBcns + slot) * pf->D.nTag), 0x3f800000,
+                                       (size_t)pf->D.nTag, pf->stream));
     pf->fl[f].bcnInit[slot] = initialized != 0;
     return 0;
 }

@@ -7,15 +7,20 @@
 // Many SLAM filters ("a batch", BASELINE.json configs[4]) are one grid dimension more; filters never interact.
 //
 // One deposit (particleFilter.c:193-211) is three launches for the whole batch, no host sync:
-//   k_slam_gate   grid (nTag, F): the measured beacon's row i -- beacon VIO motion (pfMeasurement.c:78-106), range
-//                 gate against tag particle i AFTER its own VIO motion (:127-152; the tag motion is recomputed
-//                 from the same Philox counters, not yet stored), row weight sum.                [HBM: 20 B r + 4..20 B w]
+//   k_slam_gate_rows grid (nTag, F): the measured beacon's row i in ONE pass over its 20 B/particle -- beacon VIO motion
+//                 (pfMeasurement.c:78-106), range gate against tag particle i AFTER its own VIO motion (:127-152; the
+//                 tag motion is recomputed from the same Philox counters, not yet stored), row weight sum, and the row's
+//                 own resample-or-normalise step (_resampleBcn, pfResample.c:141-201) under the assumption that the tag
+//                 particles will NOT be resampled (the common case).  A resampled row is final; a normalised row keeps
+//                 its gated weights and only records the factor N/s (rowScale, multiplied in by the next reader), so
+//                 that the rare forced pass below still finds the weights the reference would resample from.
 //   k_slam_tag    grid (F): tag VIO motion (:51-76), w_i *= rowsum_i, ESS test, resample or normalise the tag
 //                 particles (pfResample.c:86-139).                                               [tiny]
-//   k_slam_rows   grid (nTag, B, F): every row that has something to do -- VIO motion of the other beacons, the
-//                 first-range spawn (pfInit.c:34-45), and _resampleBcn (pfResample.c:141-201): of every initialised
-//                 beacon, forced, if the tag particles were resampled; else of the measured beacon only.  Rows with
-//                 nothing to do exit before touching memory.                                     [HBM: 20 B r + 20 B w]
+//   k_slam_rows   grid (nTag, B, F): what is left -- VIO motion of the other beacons, the first-range spawn
+//                 (pfInit.c:34-45), and, only if the tag particles WERE resampled, the forced _resampleBcn of every
+//                 initialised beacon (pfResample.c:122-130); rows of the measured beacon that the first kernel
+//                 already resampled would come out identical (same weights, same Philox counters) and are only
+//                 re-spawned around the NEW tag particle where the respawn rule fired.  Idle rows exit at once.
 // Noise: Philox sub-streams keyed (seed of the filter, stream = 0 for the tag / slot+1 for a beacon, epoch = deposit
 // count) and indexed by the particle's position in its array, as the oracle's Philox mode (oracle/pf_oracle.c).
 #pragma once
@@ -112,7 +117,7 @@ struct SmallLds {
 __device__ __forceinline__ SmallDecision small_filter_update(Row4& r, const float (&sn)[4], const float (&cs)[4], int j0, int n,
                                                              SmallLds& L, const RngKey& key, uint64_t index0, uint64_t rsIndex,
                                                              float range, float stdRange, bool allowSpawn, bool force,
-                                                             float cx, float cy, float cz)
+                                                             float cx, float cy, float cz, bool lazyNorm = false)
 {
     // pfResample.c:93-106 / :151-164: float products, added in double; inclusive CDF by a block scan
     double acc[4] = { 0, 0, 0, 0 };     // (unused), ss, c, sn
@@ -156,7 +161,7 @@ __device__ __forceinline__ SmallDecision small_filter_update(Row4& r, const floa
             }
             r.w[k] = 1.0f;
         }
-    } else {
+    } else if (!lazyNorm) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (j0 + k < n) r.w[k] *= d.m;              // pfResample.c:133-137 / :195-199
@@ -164,13 +169,19 @@ __device__ __forceinline__ SmallDecision small_filter_update(Row4& r, const floa
     return d;
 }
 
-// ------------------------------------------------------------------ gate of the measured beacon
-__global__ __launch_bounds__(kThreads) void k_slam_gate(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
-                                                       const Motion* __restrict__ bcnMo, float* __restrict__ rowSum)
+// ------------------------------------------------------------------ the measured beacon: gate + row step, one pass
+// rowScale[slot row]: pending factor on the stored weights of that row (1 after a resample / spawn).
+// rowFlag[f * nTag + i]: 0 = row i was normalised (lazily), 1 + numSpawn = it was resampled here.
+__global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
+                                                            const Motion* __restrict__ bcnMo, float* __restrict__ rowSum,
+                                                            float* __restrict__ rowScale, int* __restrict__ rowFlag,
+                                                            int* __restrict__ forcedCount)
 {
     const int f = blockIdx.y, i = blockIdx.x;
+    if (f == 0 && i == 0 && threadIdx.x == 0) *forcedCount = 0;         // filled by k_slam_tag, read by k_slam_rows_forced
     const SlamStep st = many ? many[f] : one;
     if (st.mode != 1) return;
+    __shared__ SmallLds L;
     __shared__ double red[4];
 
     // tag particle i after its VIO motion (stored by k_slam_tag, which runs after every row has read the old one)
@@ -183,6 +194,8 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate(SlamPtrs P, SlamDims D, 
 
     const int c = st.target, n = D.nBcn, j0 = threadIdx.x * 4;
     const size_t base = slam_row_base(D, f, c, i);
+    const size_t srow = ((size_t)f * D.maxBcns + c) * D.nTag + i;
+    const float scale = rowScale[srow];
     const float* const src[5] = { P.bcn[0], P.bcn[1], P.bcn[2], P.bcn[3], P.bcn[4] };
     Row4 r;
     row_load(src, base, j0, n, r);
@@ -192,18 +205,20 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate(SlamPtrs P, SlamDims D, 
     const bool smallTurn = mo.stdTheta <= 1e-4f;
     const RngKey key{ st.seed, (uint32_t)(c + 1), st.epoch };
     bool thetaChanged = false;
+    float sn[4] = { 0, 0, 0, 0 }, cs[4] = { 1, 1, 1, 1 };
     double sum[1] = { 0.0 };
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int j = j0 + k;
         if (j >= n) continue;
+        r.w[k] *= scale;                    // pending normalisation of an earlier deposit (pfResample.c:195-199)
         if (moving) {
-            float sn, cs;
-            motion_particle(key, (uint64_t)i * n + j, mo, smallTurn, r.x[k], r.y[k], r.z[k], r.th[k], sn, cs);
+            motion_particle(key, (uint64_t)i * n + j, mo, smallTurn, r.x[k], r.y[k], r.z[k], r.th[k], sn[k], cs[k]);
         } else {
             const float t2 = wrap_two_pi(r.th[k]);
             thetaChanged |= (t2 != r.th[k]);
             r.th[k] = t2;
+            sincos_bounded(t2, sn[k], cs[k]);
         }
         // pfMeasurement.c:142-147
         const float dx = tx - r.x[k], dy = ty - r.y[k], dz = tz - r.z[k];
@@ -211,8 +226,14 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate(SlamPtrs P, SlamDims D, 
         if (fabsf(pRange - st.range) > st.thresh) r.w[k] *= st.minWeight;
         sum[0] += r.w[k];
     }
+    block_sum<1>(sum, red);
+    if (threadIdx.x == 0) rowSum[(size_t)f * D.nTag + i] = (float)sum[0];      // pfMeasurement.c:148-150: tp->w *= bcnSum
+
+    // _resampleBcn(force = 0) of this row; the normalisation stays pending in rowScale
+    const SmallDecision d = small_filter_update(r, sn, cs, j0, n, L, key, (uint64_t)i * n, (uint64_t)i, st.range, st.stdRange, true,
+                                                false, tx, ty, tz, true);
     row_store1(P.bcn[0], base, j0, n, r.w);
-    if (moving) {
+    if (moving || d.resample) {
         row_store1(P.bcn[1], base, j0, n, r.x);
         row_store1(P.bcn[2], base, j0, n, r.y);
         row_store1(P.bcn[3], base, j0, n, r.z);
@@ -220,13 +241,16 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate(SlamPtrs P, SlamDims D, 
     } else if (thetaChanged) {
         row_store1(P.bcn[4], base, j0, n, r.th);
     }
-    block_sum<1>(sum, red);
-    if (threadIdx.x == 0) rowSum[(size_t)f * D.nTag + i] = (float)sum[0];      // pfMeasurement.c:148-150: tp->w *= bcnSum
+    if (threadIdx.x == 0) {
+        rowScale[srow] = d.resample ? 1.0f : d.m;
+        rowFlag[(size_t)f * D.nTag + i] = d.resample ? 1 + d.numSpawn : 0;
+    }
 }
 
 // ------------------------------------------------------------------ the tag particles of every filter
 __global__ __launch_bounds__(kThreads) void k_slam_tag(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
-                                                      const float* __restrict__ rowSum, int* __restrict__ tagBranch)
+                                                      const float* __restrict__ rowSum, int* __restrict__ tagBranch,
+                                                      int* __restrict__ forcedList, int* __restrict__ forcedCount)
 {
     const int f = blockIdx.x;
     const SlamStep st = many ? many[f] : one;
@@ -264,25 +288,30 @@ __global__ __launch_bounds__(kThreads) void k_slam_tag(SlamPtrs P, SlamDims D, S
     row_store1(P.tag[2], base, j0, n, r.y);
     row_store1(P.tag[3], base, j0, n, r.z);
     row_store1(P.tag[4], base, j0, n, r.th);
-    if (threadIdx.x == 0) tagBranch[f] = branch;
+    if (threadIdx.x == 0) {
+        tagBranch[f] = branch;
+        if (branch) forcedList[atomicAdd(forcedCount, 1)] = f;     // order irrelevant: filters are independent
+    }
 }
 
-// ------------------------------------------------------------------ beacon rows: motion, spawn, _resampleBcn
-__global__ __launch_bounds__(kThreads) void k_slam_rows(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
-                                                       const Motion* __restrict__ bcnMo, const int* __restrict__ tagBranch)
-{
-    const int f = blockIdx.z, c = blockIdx.y, k = blockIdx.x;
-    const SlamStep st = many ? many[f] : one;
-    if (st.mode == 0) return;
+// ------------------------------------------------------------------ beacon rows: motion, spawn, forced _resampleBcn
+// One row (tag particle k) of one beacon slot c: first-range spawn, VIO motion, forced _resampleBcn.  Called by every
+// thread of the workgroup with the same arguments (it has a barrier behind workgroup-uniform conditions).
+__device__ __forceinline__ void slam_row_work(const SlamPtrs& P, const SlamDims& D, const SlamStep& st, const Motion* __restrict__ bcnMo,
+                                              bool forcedPass, float* __restrict__ rowScale, const int* __restrict__ rowFlag,
+                                              SmallLds& L, int f, int c, int k)
+{   // forcedPass = false: the work the host knows about (spawn, motion); true: the forced resample after a tag resample
     const bool isTarget = c == st.target;
     const bool active = (st.activeMask >> c) & 1u;     // one of allBcns[]: takes the VIO commit and a forced resample
     if (!active && !isTarget) return;
     const int n = D.nBcn, j0 = threadIdx.x * 4;
     const size_t base = slam_row_base(D, f, c, k);
+    const size_t srow = ((size_t)f * D.maxBcns + c) * D.nTag + k;
     const RngKey key{ st.seed, (uint32_t)(c + 1), st.epoch };
     const size_t ti = (size_t)f * D.tagStride + k;
 
     if (st.mode == 2 && isTarget) {
+        if (forcedPass) return;
         // pfInit.c:34-45: the beacon's particles on the range shell around each (moved) tag particle
         const float tx = P.tag[1][ti], ty = P.tag[2][ti], tz = P.tag[3][ti];
         Row4 r;
@@ -299,21 +328,48 @@ __global__ __launch_bounds__(kThreads) void k_slam_rows(SlamPtrs P, SlamDims D, 
         row_store1(P.bcn[2], base, j0, n, r.y);
         row_store1(P.bcn[3], base, j0, n, r.z);
         row_store1(P.bcn[4], base, j0, n, r.th);
+        if (threadIdx.x == 0) rowScale[srow] = 1.0f;
         return;
     }
     if (!((st.initMask >> c) & 1u)) return;     // not yet spawned: nothing to move (the spawn overwrites it all)
 
-    // the measured beacon's motion was applied by k_slam_gate
-    const bool moving = ((st.movingMask >> c) & 1u) && !(isTarget && st.mode == 1);
-    const int tb = tagBranch[f];
-    // pfResample.c:122-137: tag particles resampled -> every initialised beacon, forced; else the measured one
-    const bool takes = st.mode == 1 && (tb != 0 ? active : isTarget);
-    if (!moving && !takes) return;
+    const bool measured = isTarget && st.mode == 1;     // its motion, gate and unforced row step ran in k_slam_gate_rows
+    const bool moving = !forcedPass && ((st.movingMask >> c) & 1u) && !measured;
+    // pfResample.c:122-130: tag particles resampled -> every initialised beacon of allBcns[], forced
+    const bool forced = forcedPass && st.mode == 1 && active;
+    if (!moving && !forced) return;
 
-    __shared__ SmallLds L;
+    const float tx = P.tag[1][ti], ty = P.tag[2][ti], tz = P.tag[3][ti];   // tag particle k as it is NOW (respawn centre)
+    if (forced && measured) {
+        const int flag = rowFlag[(size_t)f * D.nTag + k];
+        if (flag > 0) {
+            // Already resampled by k_slam_gate_rows from the very weights, CDF and Philox counters a forced pass would
+            // use: identical offspring.  Only the respawned head (pfResample.c:190-192) must sit around the NEW tag k.
+            const int numSpawn = flag - 1;
+            if (j0 >= numSpawn) return;
+            Row4 r;
+            const float* const src[5] = { P.bcn[0], P.bcn[1], P.bcn[2], P.bcn[3], P.bcn[4] };
+            row_load(src, base, j0, n, r);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + q;
+                if (j < numSpawn && j < n) spawn_from_range(key, (uint64_t)k * n + j, tx, ty, tz, st.range, st.stdRange, r.x[q], r.y[q], r.z[q], r.th[q]);
+            }
+            row_store1(P.bcn[1], base, j0, n, r.x);
+            row_store1(P.bcn[2], base, j0, n, r.y);
+            row_store1(P.bcn[3], base, j0, n, r.z);
+            row_store1(P.bcn[4], base, j0, n, r.th);
+            return;
+        }
+    }
+
+    __syncthreads();            // the previous beacon's pass through this function is done with L
     const float* const src[5] = { P.bcn[0], P.bcn[1], P.bcn[2], P.bcn[3], P.bcn[4] };
     Row4 r;
     row_load(src, base, j0, n, r);
+    // the measured beacon's row holds its gated weights (its rowScale is the factor of the step that is being redone
+    // as a forced resample: not applied); every other row carries the pending factor of an earlier deposit
+    const float scale = measured ? 1.0f : rowScale[srow];
     Motion mo{};
     if (moving) mo = bcnMo[(size_t)f * D.maxBcns + c];
     const bool smallTurn = mo.stdTheta <= 1e-4f;
@@ -329,15 +385,47 @@ __global__ __launch_bounds__(kThreads) void k_slam_rows(SlamPtrs P, SlamDims D, 
             sincos_bounded(r.th[q], sn[q], cs[q]);
         }
     }
-    if (takes) {
-        const float tx = P.tag[1][ti], ty = P.tag[2][ti], tz = P.tag[3][ti];   // respawn centre: tag particle k as it is NOW
-        small_filter_update(r, sn, cs, j0, n, L, key, (uint64_t)k * n, (uint64_t)k, st.range, st.stdRange, true, tb != 0, tx, ty, tz);
+    if (forced) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r.w[q] *= scale;
+        small_filter_update(r, sn, cs, j0, n, L, key, (uint64_t)k * n, (uint64_t)k, st.range, st.stdRange, true, true, tx, ty, tz);
         row_store1(P.bcn[0], base, j0, n, r.w);
+        if (threadIdx.x == 0) rowScale[srow] = 1.0f;
     }
     row_store1(P.bcn[1], base, j0, n, r.x);
     row_store1(P.bcn[2], base, j0, n, r.y);
     row_store1(P.bcn[3], base, j0, n, r.z);
     row_store1(P.bcn[4], base, j0, n, r.th);
+}
+
+// Pass A, grid (nTag, F), launched only when the host knows of a first range or a moving beacon in the batch.
+__global__ __launch_bounds__(kThreads) void k_slam_rows(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
+                                                       const Motion* __restrict__ bcnMo, float* __restrict__ rowScale,
+                                                       const int* __restrict__ rowFlag)
+{
+    const int f = blockIdx.y, k = blockIdx.x;
+    const SlamStep st = many ? many[f] : one;
+    if (st.mode == 0 || (st.mode != 2 && st.movingMask == 0u)) return;
+    __shared__ SmallLds L;
+    for (int c = 0; c < D.maxBcns; ++c) slam_row_work(P, D, st, bcnMo, false, rowScale, rowFlag, L, f, c, k);
+}
+
+// Pass B, grid (nTag, min(F, 64)): the filters whose tag particles k_slam_tag resampled (it lists them; usually none,
+// and then these few workgroups leave at once -- one workgroup per row of the whole batch, as before, cost 46..136 us
+// per deposit in dispatching workgroups that had nothing to do).
+__global__ __launch_bounds__(kThreads) void k_slam_rows_forced(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
+                                                              const Motion* __restrict__ bcnMo, float* __restrict__ rowScale,
+                                                              const int* __restrict__ rowFlag, const int* __restrict__ forcedList,
+                                                              const int* __restrict__ forcedCount)
+{
+    const int k = blockIdx.x;
+    const int cnt = *forcedCount;
+    __shared__ SmallLds L;
+    for (int q = blockIdx.y; q < cnt; q += gridDim.y) {
+        const int f = forcedList[q];
+        const SlamStep st = many ? many[f] : one;
+        for (int c = 0; c < D.maxBcns; ++c) slam_row_work(P, D, st, bcnMo, true, rowScale, rowFlag, L, f, c, k);
+    }
 }
 
 // ------------------------------------------------------------------ pose estimates
@@ -364,7 +452,7 @@ __global__ __launch_bounds__(kThreads) void k_slam_tag_pose(SlamPtrs P, SlamDims
 // particleFilter.c:353-378, inner loop: per tag particle i the weighted sums of its beacon row, folded into the
 // row's contribution w1 * (sum2 / s2) exactly as the reference forms it (float), -> rowTerms[f][i][6]
 __global__ __launch_bounds__(kThreads) void k_slam_bcn_rows_pose(SlamPtrs P, SlamDims D, const int* __restrict__ slotOf,
-                                                                float* __restrict__ rowTerms)
+                                                                const float* __restrict__ rowScale, float* __restrict__ rowTerms)
 {
     __shared__ double red[4 * 6];
     const int f = blockIdx.y, i = blockIdx.x, n = D.nBcn, j0 = threadIdx.x * 4;
@@ -373,13 +461,14 @@ __global__ __launch_bounds__(kThreads) void k_slam_bcn_rows_pose(SlamPtrs P, Sla
     const float* const src[5] = { P.bcn[0], P.bcn[1], P.bcn[2], P.bcn[3], P.bcn[4] };
     Row4 r;
     row_load(src, slam_row_base(D, f, c, i), j0, n, r);
+    const float scale = rowScale[((size_t)f * D.maxBcns + c) * D.nTag + i];
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (j0 + k >= n) continue;
         float sn, cs;
         sincos_bounded(r.th[k], sn, cs);
-        const float w = r.w[k];
+        const float w = r.w[k] * scale;
         acc[0] += w; acc[1] += w * r.x[k]; acc[2] += w * r.y[k]; acc[3] += w * r.z[k]; acc[4] += w * cs; acc[5] += w * sn;
     }
     block_sum<6>(acc, red);
