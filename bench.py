@@ -31,7 +31,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # SURVEY.md 8d / BASELINE.md: algorithmic (compulsory) HBM bytes per particle, SoA f32
-ALG_BYTES = {"stream": 44, "stream_static": 28, "resample": 40}
+# algorithmic bytes per particle.  The two fused kernels do the work of the resample (40) AND of
+# the following deposit's streaming pass (44 with motion / 28 without) in one launch; what they really move is
+# 40 B per particle (read w,x,y,z,theta of the ancestors, write them for the offspring) -- see "traffic".
+ALG_BYTES = {"stream": 44, "stream_static": 28, "resample": 40, "resample_stream": 84, "resample_static": 68}
+KERNEL_OF = {"stream": "k_loc_stream<motion,gate>", "stream_static": "k_loc_stream<gate>", "resample": "k_loc_resample",
+             "resample_stream": "k_loc_resample_deposit<motion>", "resample_static": "k_loc_resample_deposit<static>"}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -172,6 +177,7 @@ def main():
     ap.add_argument("--force-branch", type=int, default=-1, help="-1 reference test, 0 never resample, 1 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="timed region without per-kernel HIP events (no roofline)")
+    ap.add_argument("--undeferred", action="store_true", help="one resample kernel per deposit (pfx_loc_set_deferred(0))")
     ap.add_argument("--workload", default="config3", choices=["config3", "config5"])
     ap.add_argument("--slam-filters", type=int, default=512, help="config5: SLAM tags per GPU")
     ap.add_argument("--slam-bcns", type=int, default=4, help="config5: beacons per tag")
@@ -220,6 +226,8 @@ def main():
         from slam3d_amd.sharded import ShardedLocFilter
         pf = ShardedLocFilter(n * world, seed=123456789, device=local)
     pf.set_force_branch(args.force_branch)
+    if args.undeferred and world == 1 and not force_sharded:
+        pf.set_deferred(False)
 
     def barrier():
         if world > 1:
@@ -234,7 +242,7 @@ def main():
     barrier()
 
     if not args.no_kernel_events:
-        pf.profile_begin(4 * K * 3 + 16)
+        pf.profile_begin(4 * K * 4 + 16)
     barrier()
     t0 = time.perf_counter()
     for k in range(W, W + K):
@@ -256,13 +264,14 @@ def main():
     if rank == 0:
         names = pfm.DeviceParticleFilterLoc.KINDS
         per = {}
-        for nm in ("stream", "stream_static", "resample"):
+        for nm in ("stream", "stream_static", "resample", "resample_stream", "resample_static"):
             sel = ms[kinds == names.index(nm)]
-            if nm == "resample" and world == 1:
-                # a resample launch on a normalise-only step exits at once; count only the real ones,
-                # identified by the device-side branch log (one decision per launch, same order)
-                dec = branches[-sel.shape[0]:] if sel.shape[0] else branches[:0]
-                sel = sel[dec.astype(bool)] if dec.shape[0] == sel.shape[0] else sel
+            # Launches that exit at once are not counted: a resample launch after a normalise-only decision, and, with
+            # deferred resampling, whichever of k_loc_resample_deposit / k_loc_stream the previous decision (known on
+            # the device only) left nothing to do.  An empty launch takes a few microseconds, a real one at least
+            # twenty times that, so a quarter of the longest launch of the class separates them.
+            if sel.shape[0]:
+                sel = sel[sel > 0.25 * sel.max()]
             if sel.shape[0]:
                 avg_ms = float(sel.mean())
                 gbs = ALG_BYTES[nm] * n / (avg_ms * 1e-3) / 1e9
@@ -277,7 +286,7 @@ def main():
         roof = None
         if dominant:
             d = per[dominant]
-            roof = {"bound": "hbm", "kernel": "k_loc_" + ("resample" if dominant == "resample" else "stream"),
+            roof = {"bound": "hbm", "kernel": KERNEL_OF[dominant],
                     "variant": dominant, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": d["frac"], "traffic": traffic, "avg_launch_ms": d["avg_ms"], "launches": d["launches"],
                     "alg_bytes_per_particle": d["alg_bytes_per_particle"]}
@@ -297,6 +306,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"one filter sharded by particle range over {world} GPUs, "
                                                                        "RCCL all-gather of per-GPU sums per deposit",
                        "force_branch": args.force_branch, "resample_fraction": frac_a,
+                       "deferred_resampling": not (args.undeferred or world > 1 or force_sharded),
                        "rng": "Philox4x32-10 key 123456789", "final_position_error_m": err},
             "roofline": roof, "kernels": per, "cpu_baseline": cpu,
         }

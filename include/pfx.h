@@ -30,7 +30,9 @@ enum { PFX_P_VIO = 1, PFX_P_RSTART = 2, PFX_P_JITTER = 3, PFX_P_SPAWN = 4 };
 enum { PFX_K_STREAM = 0,        /* k_loc_stream with VIO motion (reads and writes all five arrays) */
        PFX_K_DECIDE = 1, PFX_K_RESAMPLE = 2, PFX_K_SPAWN = 3, PFX_K_POSE = 4,
        PFX_K_STREAM_STATIC = 5, /* k_loc_stream without motion (writes the weights only) */
-       PFX_K_COUNT = 6 };
+       PFX_K_RESAMPLE_STREAM = 6,   /* k_loc_resample_deposit: deferred resampling + the next deposit, with motion */
+       PFX_K_RESAMPLE_STATIC = 7,   /* the same without motion */
+       PFX_K_COUNT = 8 };
 
 /* ---- library ---- */
 const char* pfx_version(void);
@@ -53,6 +55,11 @@ int      pfx_loc_sync(pfx_loc* pf);                           /* wait until queu
 /* -1 (default): the reference's ESS / respawn test picks the branch (pfResample.c:58); 0: never resample;
  * 1: resample on every deposit (the worst-case-traffic run of BASELINE.json config 3) */
 int      pfx_loc_set_force_branch(pfx_loc* pf, int force);
+/* 1 (default): the resample kernel a deposit calls for (pfResample.c:70-76) is deferred until the next deposit and
+ * then runs fused with that deposit's motion + gate + sums (one pass over the offspring instead of two), or until
+ * something else reads the particles; 0: every deposit launches its own resample kernel.  Same particles either
+ * way.  Sharded filters and ancestor recording always run undeferred. */
+int      pfx_loc_set_deferred(pfx_loc* pf, int enable);
 
 /* the reference's four operations (particleFilter.c:70-104, 178-191, 213-226, 248-291) */
 void     pfx_loc_deposit_vio(pfx_loc* pf, double t, float x, float y, float z, float dist);

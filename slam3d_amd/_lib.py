@@ -48,6 +48,7 @@ def lib() -> C.CDLL:
     sig("pfx_loc_set_stream", i, vp, vp)
     sig("pfx_loc_sync", i, vp)
     sig("pfx_loc_set_force_branch", i, vp, i)
+    sig("pfx_loc_set_deferred", i, vp, i)
     sig("pfx_loc_deposit_vio", None, vp, d, f, f, f, f)
     sig("pfx_loc_deposit_range", i, vp, f, f, f, f, f)
     sig("pfx_loc_deposit_rssi", i, vp, f, f, f, i)

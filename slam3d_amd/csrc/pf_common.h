@@ -278,6 +278,50 @@ __device__ __forceinline__ void block_sum_store(const double (&v)[K], double* ld
     }
 }
 
+// The same result with a quarter of the LDS, for kernels whose occupancy hangs on it: the four lanes of a quad are
+// added first with two DPP quad permutes per double (vector-ALU moves, not LDS-crossbar shuffles), one lane per
+// quad parks the sum, K*8 threads add eight of them each, K threads add the eight partials.  Must be reached by
+// all 256 threads.  `lds` holds K*64 doubles.
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K>
+__device__ __forceinline__ double block_sum_quads(const double (&v)[K], double* lds)
+{   // returns total k in thread k (k < K), 0 elsewhere
+    const int tid = threadIdx.x;
+    __syncthreads();                        // a previous call's last reads of lds
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double s = v[k];
+        s += quad_perm_f64<0xB1>(s);        // lanes 1 0 3 2
+        s += quad_perm_f64<0x4E>(s);        // lanes 2 3 0 1
+        if ((tid & 3) == 0) lds[k * 64 + (tid >> 2)] = s;
+    }
+    __syncthreads();
+    if (tid < K * 8) {
+        const int k = tid >> 3, j = tid & 7;
+        const double* p = lds + k * 64 + j;
+        double s = p[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += p[8 * i];
+        lds[k * 64 + j] = s;
+    }
+    __syncthreads();
+    double r = 0.0;
+    if (tid < K) {
+        const double* p = lds + tid * 64;
+        r = p[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) r += p[j];
+    }
+    return r;
+}
+
 // Inclusive scan of one double per thread across a 256-thread block.  `lds` holds 4 doubles.
 __device__ __forceinline__ double block_inclusive_scan(double v, double* lds, double& block_total)
 {

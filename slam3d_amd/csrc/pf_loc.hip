@@ -96,6 +96,14 @@ struct pfx_loc {
     unsigned char* branchLog = nullptr; // kBranchLogSize
     int* anc = nullptr;             // n, only while recording
     bool recordAnc = false;
+    // deferred resampling (unsharded filters): the resample kernel of a deposit waits for the next deposit, which
+    // then runs fused with it (k_loc_resample_deposit), or for anything else that reads the particles (materialise)
+    bool deferEnabled = true;
+    bool deferOpen = false;         // a decision has been taken whose resample kernel has not been launched
+    RngKey deferKey{};              // Philox key and respawn shell of that deposit
+    float deferArg[5] = { 0, 0, 0, 0, 0 };
+    double* pieceSums = nullptr;    // 2 * numTiles * kSumsPerTile: per (source tile, destination tile) sums
+    int* pieceSlots = nullptr;      // head slot [numTiles], tail slot [numTiles]
     LocCtl* ctl = nullptr;
     LocCtl* hostCtl = nullptr;      // pinned
     uint32_t seed = 0, streamId = 0, epoch = 0;
@@ -161,14 +169,14 @@ int launch_set_ctl(pfx_loc* pf, int cur, int branch, float wscale, int keepCur, 
     return check_launch("k_loc_set_ctl");
 }
 
-int launch_stream(pfx_loc* pf, bool motion, bool gate, const Motion& mo, const Gate& ga)
+int launch_stream(pfx_loc* pf, bool motion, bool gate, const Motion& mo, const Gate& ga, bool skipIfResampled = false)
 {
     ProfScope ps(pf, motion ? PFX_K_STREAM : PFX_K_STREAM_STATIC);
     const dim3 grid(pf->numTiles), block(kThreads);
     const RngKey key = key_of(pf);
 #define PF_LAUNCH_STREAM(M, G) \
     hipExtLaunchKernelGGL((k_loc_stream<M, G>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->tileSums, pf->n, \
-                          pf->selfBegin, key, mo, ga)
+                          pf->selfBegin, key, mo, ga, skipIfResampled ? 1 : 0)
     if (motion && gate) PF_LAUNCH_STREAM(true, true);
     else if (motion) PF_LAUNCH_STREAM(true, false);
     else if (gate) PF_LAUNCH_STREAM(false, true);
@@ -177,11 +185,13 @@ int launch_stream(pfx_loc* pf, bool motion, bool gate, const Motion& mo, const G
     return check_launch("k_loc_stream");
 }
 
-int launch_decide(pfx_loc* pf, float range, bool localOnly = false)
+int launch_decide(pfx_loc* pf, float range, bool localOnly = false, bool pieces = false)
 {
     ProfScope ps(pf, PFX_K_DECIDE);
+    TilePieces tp{ nullptr, nullptr, nullptr };
+    if (pieces) tp = TilePieces{ pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles };
     hipExtLaunchKernelGGL(k_loc_chunks, dim3(pf->numChunks), dim3(kChunkTiles), 0, pf->stream, ps.a(), nullptr, 0, pf->tileSums,
-                          pf->tileIncl, pf->chunkSums, pf->numTiles);
+                          pf->tileIncl, pf->chunkSums, pf->numTiles, pf->ctl, tp);
     if (check_launch("k_loc_chunks")) return -1;
     if (localOnly)
         hipExtLaunchKernelGGL((k_loc_decide<true>), dim3(1), dim3(kDecideThreads), 0, pf->stream, nullptr, ps.b(), 0, pf->ctl,
@@ -192,7 +202,7 @@ int launch_decide(pfx_loc* pf, float range, bool localOnly = false)
     return check_launch("k_loc_decide");
 }
 
-int launch_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+int launch_resample(pfx_loc* pf, const RngKey& key, float bx, float by, float bz, float range, float stdRange)
 {
     ProfScope ps(pf, PFX_K_RESAMPLE);
     const dim3 grid(pf->numTiles), block(kThreads);
@@ -201,11 +211,38 @@ int launch_resample(pfx_loc* pf, float bx, float by, float bz, float range, floa
     st.cap = pf->stageSlab ? (long long)pf->stageCap : 0;
     if (pf->recordAnc)
         hipExtLaunchKernelGGL((k_loc_resample<true>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase, pf->tileIncl,
-                           pf->anc, pf->numTiles, pf->n, st, key_of(pf), bx, by, bz, range, stdRange);
+                           pf->anc, pf->numTiles, pf->n, st, key, bx, by, bz, range, stdRange);
     else
         hipExtLaunchKernelGGL((k_loc_resample<false>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase, pf->tileIncl,
-                           (int*)nullptr, pf->numTiles, pf->n, st, key_of(pf), bx, by, bz, range, stdRange);
+                           (int*)nullptr, pf->numTiles, pf->n, st, key, bx, by, bz, range, stdRange);
     return check_launch("k_loc_resample");
+}
+
+// The deferred resampling of the previous deposit fused with the current one (exits unless that decision was to
+// resample; k_loc_stream, launched next with skipIfResampled, covers the other case).
+int launch_resample_deposit(pfx_loc* pf, bool motion, const Motion& mo, const Gate& ga)
+{
+    ProfScope ps(pf, motion ? PFX_K_RESAMPLE_STREAM : PFX_K_RESAMPLE_STATIC);
+    const dim3 grid(pf->numTiles), block(kThreads);
+    const float* a = pf->deferArg;
+#define PF_LAUNCH_RD(M) \
+    hipExtLaunchKernelGGL((k_loc_resample_deposit<M>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase, \
+                          pf->tileIncl, pf->numTiles, (int)pf->n, pf->deferKey, a[0], a[1], a[2], a[3], a[4], key_of(pf), mo, ga, \
+                          pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles)
+    if (motion) PF_LAUNCH_RD(true);
+    else PF_LAUNCH_RD(false);
+#undef PF_LAUNCH_RD
+    return check_launch("k_loc_resample_deposit");
+}
+
+// Launch the resample kernel a deposit left pending.  Called by everything that reads or replaces the particles
+// other than the next deposit.
+int materialise(pfx_loc* pf)
+{
+    if (!pf->deferOpen) return 0;
+    pf->deferOpen = false;
+    const float* a = pf->deferArg;
+    return launch_resample(pf, pf->deferKey, a[0], a[1], a[2], a[3], a[4]);
 }
 
 int launch_spawn(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
@@ -259,6 +296,8 @@ void free_device(pfx_loc* pf)
     if (pf->chunkSums) hipFree(pf->chunkSums);
     if (pf->chunkBase) hipFree(pf->chunkBase);
     if (pf->anc) hipFree(pf->anc);
+    if (pf->pieceSums) hipFree(pf->pieceSums);
+    if (pf->pieceSlots) hipFree(pf->pieceSlots);
     if (pf->branchLog) hipFree(pf->branchLog);
     if (pf->ctl) hipFree(pf->ctl);
     if (pf->hostCtl) hipHostFree(pf->hostCtl);
@@ -288,6 +327,10 @@ int alloc_device(pfx_loc* pf)
     PF_HIP_OK(hipMalloc((void**)&pf->chunkBase, (nc + 1) * sizeof(double)));
     PF_HIP_OK(hipMemsetAsync(pf->tileSums, 0, nt * kSumsPerTile * sizeof(double), pf->stream));
     PF_HIP_OK(hipMemsetAsync(pf->rsPart, 0, nt * kRsPerTile * sizeof(double), pf->stream));
+    PF_HIP_OK(hipMalloc((void**)&pf->pieceSums, 2 * nt * kSumsPerTile * sizeof(double)));
+    PF_HIP_OK(hipMalloc((void**)&pf->pieceSlots, 2 * nt * sizeof(int)));
+    PF_HIP_OK(hipMemsetAsync(pf->pieceSums, 0, 2 * nt * kSumsPerTile * sizeof(double), pf->stream));
+    PF_HIP_OK(hipMemsetAsync(pf->pieceSlots, 0, 2 * nt * sizeof(int), pf->stream));
     PF_HIP_OK(hipMalloc((void**)&pf->branchLog, kBranchLogSize));
     PF_HIP_OK(hipMemsetAsync(pf->branchLog, 0, kBranchLogSize, pf->stream));
     PF_HIP_OK(hipMalloc((void**)&pf->ctl, sizeof(LocCtl)));
@@ -352,6 +395,10 @@ extern "C" void pfx_loc_destroy(pfx_loc* pf)
 extern "C" int pfx_loc_reset(pfx_loc* pf, uint32_t seed, uint32_t stream_id)
 {   // particleFilter.c:32-46: scalars zeroed, not initialised; the particle arrays are left as they are
     clear_error();
+    {
+        DeviceGuard g(pf->device);
+        if (materialise(pf)) return -1;
+    }
     pf->vio = VioState();
     pf->initialized = false;
     pf->seed = seed;
@@ -373,6 +420,7 @@ extern "C" int pfx_loc_set_stream(pfx_loc* pf, void* hip_stream)
 {
     clear_error();
     DeviceGuard g(pf->device);
+    if (materialise(pf)) return -1;
     PF_HIP_OK(hipStreamSynchronize(pf->stream));
     if (pf->ownStream) { hipStreamDestroy(pf->stream); pf->ownStream = false; }
     pf->stream = (hipStream_t)hip_stream;
@@ -390,6 +438,16 @@ extern "C" int pfx_loc_sync(pfx_loc* pf)
 extern "C" int pfx_loc_set_force_branch(pfx_loc* pf, int force)
 {   // -1: the reference's ESS / respawn test decides; 0: never resample; 1: resample on every deposit
     pf->force = force < 0 ? -1 : (force ? 1 : 0);
+    return 0;
+}
+
+extern "C" int pfx_loc_set_deferred(pfx_loc* pf, int enable)
+{   // 1 (default): a resampling decision waits for the next deposit and runs fused with it; 0: every deposit
+    // launches its own resample kernel.  Same particles either way.
+    clear_error();
+    DeviceGuard g(pf->device);
+    if (!enable && materialise(pf)) return -1;
+    pf->deferEnabled = enable != 0;
     return 0;
 }
 
@@ -414,9 +472,26 @@ extern "C" int pfx_loc_deposit_range(pfx_loc* pf, float bx, float by, float bz, 
         pf->initialized = true;
         return 0;
     }
-    if (launch_stream(pf, !is_zero_motion(d), true, motion_of(d), gate_of(bx, by, bz, range, stdRange))) return -1;
-    if (launch_decide(pf, range)) return -1;
-    return launch_resample(pf, bx, by, bz, range, stdRange);
+    const bool motion = !is_zero_motion(d);
+    const Motion mo = motion_of(d);
+    const Gate ga = gate_of(bx, by, bz, range, stdRange);
+    const bool defer = pf->deferEnabled && !pf->recordAnc && pf->numShards == 1 && !pf->stageSlab;
+    if (!defer) {
+        if (materialise(pf)) return -1;
+        if (launch_stream(pf, motion, true, mo, ga)) return -1;
+        if (launch_decide(pf, range)) return -1;
+        return launch_resample(pf, key_of(pf), bx, by, bz, range, stdRange);
+    }
+    // Deferred: if the previous decision (still on the device, unknown here) was to resample, the fused kernel does
+    // that and this deposit in one pass and the streaming kernel exits; otherwise the other way round.
+    const bool open = pf->deferOpen;
+    if (open && launch_resample_deposit(pf, motion, mo, ga)) return -1;
+    if (launch_stream(pf, motion, true, mo, ga, open)) return -1;
+    if (launch_decide(pf, range, false, open)) return -1;
+    pf->deferOpen = true;
+    pf->deferKey = key_of(pf);
+    pf->deferArg[0] = bx; pf->deferArg[1] = by; pf->deferArg[2] = bz; pf->deferArg[3] = range; pf->deferArg[4] = stdRange;
+    return 0;
 }
 
 extern "C" int pfx_loc_deposit_rssi(pfx_loc* pf, float bx, float by, float bz, int rssi)
@@ -433,6 +508,7 @@ extern "C" int pfx_loc_get_tag_loc(pfx_loc* pf, double* t, float* x, float* y, f
     if (!pf->initialized) return 0;
     DeviceGuard g(pf->device);
     if (pf->poseDirty) {
+        if (materialise(pf)) return -1;
         if (launch_pose(pf)) return -1;
         if (read_ctl(pf)) return -1;
         pf->poseDirty = false;
@@ -448,6 +524,7 @@ extern "C" int pfx_loc_upload(pfx_loc* pf, const float* w, const float* x, const
     if (n != pf->n) { set_error("pfx_loc_upload: n=%lld but the filter holds %lld", (long long)n, pf->n); return -2; }
     DeviceGuard g(pf->device);
     const float* src[5] = { w, x, y, z, theta };
+    if (materialise(pf)) return -1;
     PF_HIP_OK(hipMemsetAsync(pf->slab, 0, pf->padded * 5 * sizeof(float), pf->stream));
     for (int k = 0; k < 5; ++k)
         PF_HIP_OK(hipMemcpyAsync(pf->bufs.a[0][k], src[k], (size_t)n * sizeof(float), hipMemcpyHostToDevice, pf->stream));
@@ -466,6 +543,7 @@ extern "C" int pfx_loc_download(pfx_loc* pf, float* w, float* x, float* y, float
     clear_error();
     if (n != pf->n) { set_error("pfx_loc_download: n=%lld but the filter holds %lld", (long long)n, pf->n); return -2; }
     DeviceGuard g(pf->device);
+    if (materialise(pf)) return -1;
     if (read_ctl(pf)) return -1;
     const int cur = pf->hostCtl->cur;
     float* dst[5] = { w, x, y, z, theta };
@@ -484,6 +562,7 @@ extern "C" int pfx_loc_device_arrays(pfx_loc* pf, void* d_ptrs[5], float* wscale
 {
     clear_error();
     DeviceGuard g(pf->device);
+    if (materialise(pf)) return -1;
     if (read_ctl(pf)) return -1;
     for (int k = 0; k < 5; ++k) d_ptrs[k] = pf->bufs.a[pf->hostCtl->cur][k];
     if (wscale) *wscale = pf->hostCtl->wscale;
@@ -496,6 +575,7 @@ extern "C" int pfx_loc_apply_vio(pfx_loc* pf, float dt, float dx, float dy, floa
     clear_error();
     DeviceGuard g(pf->device);
     const float d[5] = { dt, dx, dy, dz, ddist };
+    if (materialise(pf)) return -1;
     if (launch_stream(pf, true, false, motion_of(d), Gate{})) return -1;
     pf->poseDirty = true;
     return launch_set_ctl(pf, 0, 0, 1.0f, 1);
@@ -506,6 +586,7 @@ extern "C" int pfx_loc_apply_range(pfx_loc* pf, float bx, float by, float bz, fl
     clear_error();
     DeviceGuard g(pf->device);
     const float zero[5] = { 0, 0, 0, 0, 0 };
+    if (materialise(pf)) return -1;
     if (launch_stream(pf, false, true, motion_of(zero), gate_of(bx, by, bz, range, stdRange))) return -1;
     pf->poseDirty = true;
     return launch_set_ctl(pf, 0, 0, 1.0f, 1);
@@ -516,16 +597,18 @@ extern "C" int pfx_loc_resample(pfx_loc* pf, float bx, float by, float bz, float
     clear_error();
     DeviceGuard g(pf->device);
     const float zero[5] = { 0, 0, 0, 0, 0 };
+    if (materialise(pf)) return -1;
     if (launch_stream(pf, false, false, motion_of(zero), Gate{})) return -1;
     if (launch_decide(pf, range)) return -1;
     pf->poseDirty = true;
-    return launch_resample(pf, bx, by, bz, range, stdRange);
+    return launch_resample(pf, key_of(pf), bx, by, bz, range, stdRange);
 }
 
 extern "C" int pfx_loc_spawn_all(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
 {   // pfInit.c:20-25
     clear_error();
     DeviceGuard g(pf->device);
+    if (materialise(pf)) return -1;
     pf->poseDirty = true;
     return launch_spawn(pf, bx, by, bz, range, stdRange);
 }
@@ -545,6 +628,7 @@ extern "C" int pfx_loc_record_ancestors(pfx_loc* pf, int enable)
 {
     clear_error();
     DeviceGuard g(pf->device);
+    if (materialise(pf)) return -1;
     if (enable && !pf->anc) PF_HIP_OK(hipMalloc((void**)&pf->anc, (size_t)pf->n * sizeof(int)));
     pf->recordAnc = enable != 0;
     return 0;
@@ -612,6 +696,7 @@ extern "C" int pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64
     }
     if (self_begin < 0 || self_begin + pf->n > n_global) { set_error("pfx_loc_shard_config: index range outside [0, n_global)"); return -2; }
     DeviceGuard g(pf->device);
+    if (materialise(pf)) return -1;
     pf->rank = rank; pf->numShards = num_shards; pf->nGlobal = n_global; pf->selfBegin = self_begin;
     if (!pf->dAll) {
         PF_HIP_OK(hipMalloc((void**)&pf->dAll, kMaxShards * 8 * sizeof(double)));
@@ -633,6 +718,7 @@ extern "C" int pfx_loc_shard_pass1(pfx_loc* pf, float bx, float by, float bz, fl
 {
     clear_error();
     DeviceGuard g(pf->device);
+    if (materialise(pf)) return -1;
     float d[5];
     pf->epoch++;
     vio_commit(pf->vio, d);
@@ -666,7 +752,7 @@ extern "C" int pfx_loc_shard_decide_resample(pfx_loc* pf, float bx, float by, fl
                               pf->dPlanMapped, (unsigned long long)pf->epoch);
         if (check_launch("k_loc_shard_decide")) return -1;
     }
-    return launch_resample(pf, bx, by, bz, range, stdRange);
+    return launch_resample(pf, key_of(pf), bx, by, bz, range, stdRange);
 }
 
 // Wait for the plan of the current deposit (polls the pinned copy; falls back to a stream synchronisation).
@@ -744,6 +830,7 @@ extern "C" int pfx_loc_shard_pose_sums(pfx_loc* pf, double out[6])
 {
     clear_error();
     DeviceGuard g(pf->device);
+    if (materialise(pf)) return -1;
     if (launch_pose(pf)) return -1;
     if (read_ctl(pf)) return -1;
     for (int k = 0; k < 6; ++k) out[k] = pf->hostCtl->pose[k];

@@ -75,10 +75,13 @@ __device__ __forceinline__ long long first_offspring_at(double b, double rStart,
 template <bool MOTION, bool GATE>
 __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const LocCtl* __restrict__ ctl,
                                                         double* __restrict__ tileSums, long long n, long long idx0,
-                                                        RngKey key, Motion mo, Gate ga)
+                                                        RngKey key, Motion mo, Gate ga, int skipIfResampled)
 {
     // idx0: global index of local particle 0 (0 unless the filter is one shard of a larger one); the
     // Philox counter uses the global index, so the noise does not depend on how the filter is sharded
+    // skipIfResampled: the previous deposit's resampling was deferred and k_loc_resample_deposit, launched just
+    // before this kernel, has applied this deposit to the offspring as it produced them
+    if (skipIfResampled && ctl->branch == 1) return;
     __shared__ double red[7 * kThreads];
     const int cur = ctl->cur;
     const float wscale = ctl->wscale;
@@ -150,17 +153,38 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
 // Workgroup c sums the seven per-tile sums of its 256 tiles (-> chunkSums[c]) and writes the inclusive
 // prefix of the tile weights inside the chunk (-> tileIncl[t]), made non-decreasing with a max-scan so that
 // rounding in the parallel scan can never order two tile boundaries the wrong way round.
-__global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(const double* __restrict__ tileSums, double* __restrict__ tileIncl,
-                                                           double* __restrict__ chunkSums, int numTiles)
+//
+// pieces != nullptr: the deposit may have been applied by k_loc_resample_deposit (ctl->branch == 1 at this point,
+// i.e. the PREVIOUS decision was to resample).  Then the sums of tile t arrive as pieces, one per source tile that
+// produced offspring inside it, in the consecutive slots headSlot[t] .. tailSlot[t]; they are added in slot order
+// (fixed, so runs are bit-reproducible) and written to tileSums as the streaming kernel would have.
+struct TilePieces { const double* sums; const int* headSlot; const int* tailSlot; };
+
+__global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(double* __restrict__ tileSums, double* __restrict__ tileIncl,
+                                                           double* __restrict__ chunkSums, int numTiles,
+                                                           const LocCtl* __restrict__ ctl, TilePieces pieces)
 {
     __shared__ double red[4 * 7];
     __shared__ double sc[4];
     const int t = blockIdx.x * kChunkTiles + threadIdx.x;
     double v[7] = { 0, 0, 0, 0, 0, 0, 0 };
     if (t < numTiles) {
-        const double* p = tileSums + (size_t)t * kSumsPerTile;
+        double* p = tileSums + (size_t)t * kSumsPerTile;
+        if (pieces.sums != nullptr && ctl->branch == 1) {
+            int h = pieces.headSlot[t], e = pieces.tailSlot[t];
+            h = h < 0 ? 0 : h;
+            e = e >= 2 * numTiles ? 2 * numTiles - 1 : e;
+            for (int sl = h; sl <= e; ++sl) {
+                const double* q = pieces.sums + (size_t)sl * kSumsPerTile;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) v[k] = p[k];
+                for (int k = 0; k < 7; ++k) v[k] += q[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 7; ++k) p[k] = v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) v[k] = p[k];
+        }
     }
     double total;
     double incl = block_inclusive_scan(v[0], sc, total);
@@ -504,6 +528,191 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
             }
         }
     }
+}
+
+// ------------------------------------------------------------------ deferred resampling + the next deposit
+// A deposit whose decision was "resample" does not have to write its offspring before the next deposit is known:
+// the unsharded filter defers the kernel, and when the next deposit arrives this kernel produces the offspring
+// (exactly as k_loc_resample does: same CDF, same searches, same Philox counters of the deciding deposit, keyRs)
+// and applies the new deposit to each one while it is still in registers -- VIO motion (MOTION) or the heading wrap
+// of a zero motion, the range gate, and the seven weighted sums -- instead of writing 20 B, reading them back and
+// writing again in k_loc_stream.  The values stored are bit for bit those of the two-kernel sequence.
+//
+// Sums.  The next CDF needs the sums per DESTINATION tile, but a workgroup owns a SOURCE tile and its offspring
+// span [i0, i1) crosses destination tiles anywhere.  The span is walked destination tile by destination tile (a
+// thread's group of four offspring never straddles one); each piece (source tile t, destination tile d) is reduced
+// on its own and stored in slot t + d -- unique and increasing along the walk, because every step advances t or d.
+// Workgroups with an empty span store a zero piece so that the slots between a tile's first and last piece are
+// all written; the workgroups that produce a tile's first and last offspring record those slots.  k_loc_chunks
+// adds the pieces in slot order: deterministic, unlike atomics.
+template <bool MOTION>
+__global__ __launch_bounds__(kThreads) void k_loc_resample_deposit(LocBufs bufs, const LocCtl* __restrict__ ctl,
+                                                                  const double* __restrict__ chunkBase,
+                                                                  const double* __restrict__ tileIncl, int numTiles, int n,
+                                                                  RngKey keyRs, float sbx, float sby, float sbz, float srange,
+                                                                  float sstd, RngKey key, Motion mo, Gate ga,
+                                                                  double* __restrict__ pieceSums, int* __restrict__ headSlot,
+                                                                  int* __restrict__ tailSlot)
+{
+    if (ctl->branch != 1) return;           // the previous deposit only normalised: k_loc_stream does this one
+
+    __shared__ double cdf[kTile];
+    __shared__ float4 anc[kTile];
+    __shared__ double park[7 * 64];
+    __shared__ double red[4];
+    __shared__ int span[2];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int src = ctl->src, dst = ctl->dst;
+    const int tbase = t * kTile;
+    const int e0 = tbase + tid * kPerThread;
+    const float4 w4 = *reinterpret_cast<const float4*>(bufs.a[src][0] + e0);
+    const float4 x4 = *reinterpret_cast<const float4*>(bufs.a[src][1] + e0);
+    const float4 y4 = *reinterpret_cast<const float4*>(bufs.a[src][2] + e0);
+    const float4 z4 = *reinterpret_cast<const float4*>(bufs.a[src][3] + e0);
+    const float4 t4 = *reinterpret_cast<const float4*>(bufs.a[src][4] + e0);
+
+    const double rStart = ctl->rStart, rStep = ctl->rStep;
+    const double shardBase = ctl->shardBase, shardEnd = ctl->shardEnd;     // [0, S): the filter is not sharded
+    const double tileStart = tile_start_cdf(chunkBase, tileIncl, t, shardBase, shardEnd);
+    if (tid == 0) {
+        span[0] = (t == 0) ? 0 : (int)first_offspring_at(tileStart, rStart, rStep, n);
+    } else if (tid == 64) {
+        span[1] = (t == numTiles - 1)
+                      ? n
+                      : (int)first_offspring_at(tile_start_cdf(chunkBase, tileIncl, t + 1, shardBase, shardEnd), rStart, rStep, n);
+    }
+
+    const double a0 = w4.x, a1 = a0 + w4.y, a2 = a1 + w4.z, a3 = a2 + w4.w;
+    double total;
+    const double incl = block_inclusive_scan(a3, red, total);
+    const double off = tileStart + (incl - a3);
+    const int rem = n - tbase;
+    const int nValid = rem < kTile ? rem : kTile;
+    const double inf = __builtin_huge_val();
+    cdf[tid * 4 + 0] = (tid * 4 + 0 < nValid) ? off + a0 : inf;
+    cdf[tid * 4 + 1] = (tid * 4 + 1 < nValid) ? off + a1 : inf;
+    cdf[tid * 4 + 2] = (tid * 4 + 2 < nValid) ? off + a2 : inf;
+    cdf[tid * 4 + 3] = (tid * 4 + 3 < nValid) ? off + a3 : inf;
+    anc[tid * 4 + 0] = make_float4(x4.x, y4.x, z4.x, t4.x);
+    anc[tid * 4 + 1] = make_float4(x4.y, y4.y, z4.y, t4.y);
+    anc[tid * 4 + 2] = make_float4(x4.z, y4.z, z4.z, t4.z);
+    anc[tid * 4 + 3] = make_float4(x4.w, y4.w, z4.w, t4.w);
+    __syncthreads();
+    const int i0 = span[0], i1 = span[1];
+    if (i0 >= i1) {
+        // empty span at offspring position i0: a zero piece in the slot the walk would have used there
+        if (tid < 7) pieceSums[(size_t)(t + i0 / kTile) * kSumsPerTile + tid] = 0.0;
+        return;
+    }
+
+    const float hTheta = ctl->htheta;
+    const int numSpawn = ctl->numSpawn;
+    const bool smallTurn = mo.stdTheta <= 1e-4f;
+    float* __restrict__ dw = bufs.a[dst][0];
+    float* __restrict__ dx = bufs.a[dst][1];
+    float* __restrict__ dy = bufs.a[dst][2];
+    float* __restrict__ dz = bufs.a[dst][3];
+    float* __restrict__ dt = bufs.a[dst][4];
+
+    // thread k < 7 stores sum k of the piece (this source tile, destination tile d); thread 0 notes whether the
+    // piece holds the tile's first / last offspring
+    auto store_piece = [&](int d, double v) {
+        const int slot = t + d;
+        if (tid < 7) pieceSums[(size_t)slot * kSumsPerTile + tid] = v;
+        if (tid == 0) {
+            const int first = d * kTile;
+            const int last = (first + kTile < n ? first + kTile : n) - 1;
+            if (i0 <= first) headSlot[d] = slot;            // first < i1 holds: the piece is not empty
+            if (last < i1) tailSlot[d] = slot;              // last >= i0 likewise
+        }
+    };
+
+    // Groups of four offspring aligned on the destination arrays, dealt to the threads densely from the start of
+    // the span (group g0 + tid), 1024 offspring per round.  A round touches at most two destination tiles, dLo and
+    // dHi = dLo + 1: their sums are reduced separately, and a tile that continues into the next round is carried.
+    const int d1 = (i1 - 1) / kTile;
+    double carry = 0.0;
+    int carryTile = -1;
+    for (int g0 = i0 >> 2; 4 * g0 < i1; g0 += kThreads) {
+        const int e = 4 * (g0 + tid);                       // first offspring of this thread's group
+        double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        if (e < i1) {
+            int jj[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const double u = rStart + rStep * (double)(e + m);      // pfResample.c:71
+                jj[m] = upper_bound_tile(cdf, nValid, u);
+            }
+            float ow[4], ox[4], oy[4], oz[4], ot[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int i = e + m;
+                ow[m] = ox[m] = oy[m] = oz[m] = ot[m] = 0.0f;
+                if (i < i0 || i >= i1) continue;
+                if (i < numSpawn) {
+                    spawn_from_range(keyRs, (uint64_t)i, sbx, sby, sbz, srange, sstd, ox[m], oy[m], oz[m], ot[m]);
+                } else {
+                    const float4 a = anc[jj[m]];
+                    spawn_from_other(keyRs, (uint64_t)i, a.x, a.y, a.z, a.w, kHxyz, hTheta, ox[m], oy[m], oz[m], ot[m]);
+                }
+                // the new deposit on the fresh offspring (weight 1): the body of k_loc_stream
+                float wi = 1.0f, thi = ot[m], sn, cs;
+                if (MOTION) {
+                    motion_particle(key, (uint64_t)i, mo, smallTurn, ox[m], oy[m], oz[m], thi, sn, cs);
+                } else {
+                    thi = wrap_two_pi(thi);
+                    sincos_bounded(thi, sn, cs);
+                }
+                ot[m] = thi;
+                const float gx = ox[m] - ga.bx, gy = oy[m] - ga.by, gz = oz[m] - ga.bz;
+                const float pRange = sqrtf(gx * gx + gy * gy + gz * gz);
+                if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
+                ow[m] = wi;
+                acc[0] += wi;
+                acc[1] += wi * wi;
+                acc[2] += wi * cs;
+                acc[3] += wi * sn;
+                acc[4] += wi * ox[m];
+                acc[5] += wi * oy[m];
+                acc[6] += wi * oz[m];
+            }
+            if (e >= i0 && e + kPerThread <= i1) {
+                *reinterpret_cast<float4*>(dw + e) = make_float4(ow[0], ow[1], ow[2], ow[3]);
+                *reinterpret_cast<float4*>(dx + e) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+                *reinterpret_cast<float4*>(dy + e) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+                *reinterpret_cast<float4*>(dz + e) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+                *reinterpret_cast<float4*>(dt + e) = make_float4(ot[0], ot[1], ot[2], ot[3]);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int i = e + m;
+                    if (i < i0 || i >= i1) continue;
+                    dw[i] = ow[m]; dx[i] = ox[m]; dy[i] = oy[m]; dz[i] = oz[m]; dt[i] = ot[m];
+                }
+            }
+        }
+        const int dLo = (4 * g0) / kTile;
+        int dHi = (4 * (g0 + kThreads - 1)) / kTile;
+        dHi = dHi < d1 ? dHi : d1;                          // groups past the span carry zeros
+        const int myTile = e / kTile;
+        double v[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = (myTile == dLo) ? acc[k] : 0.0;
+        double lo = block_sum_quads<7>(v, park);
+        if (carryTile == dLo) lo = carry + lo;
+        else if (carryTile >= 0) store_piece(carryTile, carry);     // the previous round ended on a tile boundary
+        if (dHi != dLo) {
+            store_piece(dLo, lo);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) v[k] = (myTile == dLo) ? 0.0 : acc[k];
+            carry = block_sum_quads<7>(v, park);
+            carryTile = dHi;
+        } else {
+            carry = lo;
+            carryTile = dLo;
+        }
+    }
+    store_piece(carryTile, carry);
 }
 
 // ------------------------------------------------------------------ pose sums after a resampling step

@@ -151,6 +151,10 @@ class DeviceParticleFilterLoc:
     def set_force_branch(self, force: int):
         check(self._L.pfx_loc_set_force_branch(self._h, int(force)), "pfx_loc_set_force_branch")
 
+    def set_deferred(self, enable: bool):
+        """Deferred resampling (default on): see pfx_loc_set_deferred in include/pfx.h."""
+        check(self._L.pfx_loc_set_deferred(self._h, int(bool(enable))), "pfx_loc_set_deferred")
+
     @property
     def initialized(self) -> bool:
         return bool(self._L.pfx_loc_initialized(self._h))
@@ -221,7 +225,7 @@ class DeviceParticleFilterLoc:
     def profile_begin(self, max_records: int = 4096):
         check(self._L.pfx_loc_profile_begin(self._h, int(max_records)), "pfx_loc_profile_begin")
 
-    KINDS = ["stream", "decide", "resample", "spawn", "pose", "stream_static"]
+    KINDS = ["stream", "decide", "resample", "spawn", "pose", "stream_static", "resample_stream", "resample_static"]
 
     def profile_records(self, cap: int = 1 << 16):
         """(kind, ms) per recorded launch, in launch order; kind indexes KINDS."""
@@ -231,8 +235,8 @@ class DeviceParticleFilterLoc:
         return kind[:k].copy(), ms[:k].copy()
 
     def profile_read(self) -> dict:
-        ms = (C.c_double * 6)()
-        cnt = (C.c_int64 * 6)()
+        ms = (C.c_double * len(self.KINDS))()
+        cnt = (C.c_int64 * len(self.KINDS))()
         check(self._L.pfx_loc_profile_read(self._h, ms, cnt), "pfx_loc_profile_read")
         return {k: {"ms": ms[i], "launches": int(cnt[i])} for i, k in enumerate(self.KINDS)}
 

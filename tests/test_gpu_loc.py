@@ -323,6 +323,104 @@ def test_deposit_sequence_tracks_oracle(pfm, ora, n):
         assert np.quantile(d, 0.999) <= 1e-4
 
 
+# ------------------------------------------------------------------ deferred resampling (k_loc_resample_deposit)
+def _deposit_only(f, events):
+    for ev in events:
+        if ev[0] == "vio":
+            f.depositVio(*ev[1:])
+        elif ev[0] == "range":
+            f.depositRange(*ev[1:])
+        else:
+            f.depositRssi(*ev[1:])
+
+
+@pytest.mark.parametrize("n", [1, 1000, 1024, 1025, 5000, 70001, 1 << 20, 16000000])
+def test_deferred_resampling_equals_undeferred(pfm, n):
+    """A run of deposits with nothing read in between goes through the fused kernel (the resampling a deposit
+    decided on + the next deposit in one pass, per-destination-tile sums assembled from pieces); the same run with
+    pfx_loc_set_deferred(0) launches k_loc_resample + k_loc_stream per deposit.  Same decisions, and the particle
+    arrays must come out bit for bit the same: the fused kernel evaluates the same expressions on the same values
+    (the sums differ in their last float64 bits, which moves no decision scalar and no ancestor here)."""
+    a = pfm.DeviceParticleFilterLoc(n, seed=SEED)
+    b = pfm.DeviceParticleFilterLoc(n, seed=SEED)
+    b.set_deferred(False)
+    ev = _scene_events(24 if n <= (1 << 20) else 6)
+    for f in (a, b):
+        _deposit_only(f, ev)
+    la, lb = a.branch_log()[0], b.branch_log()[0]
+    assert np.array_equal(la, lb)
+    if n >= 1000:
+        assert 0 < la.sum() < la.shape[0]       # both kinds of decision occur, so both kernels of the pair ran
+    for c, (u, v) in enumerate(zip(a.download(), b.download())):
+        assert np.array_equal(u, v), f"array {c}"
+    pa, pb = a.getTagLoc(), b.getTagLoc()
+    assert np.abs(np.array(pa[2:], dtype=np.float64) - np.array(pb[2:], dtype=np.float64)).max() <= 1e-6
+    # and again after the read (the pending resample was materialised by the download): keeps going identically
+    ev2 = _scene_events(30)[len(ev):]
+    for f in (a, b):
+        _deposit_only(f, ev2)
+    assert np.array_equal(a.branch_log()[0], b.branch_log()[0])
+    for c, (u, v) in enumerate(zip(a.download(), b.download())):
+        assert np.array_equal(u, v), f"array {c} (second leg)"
+
+
+@pytest.mark.parametrize("n", [4096 + 5, 200000])
+def test_deferred_resampling_concentrated_weight(pfm, n):
+    """All the weight on a handful of particles: one source tile produces the offspring of many destination tiles
+    (its workgroup walks them piece by piece) and every other workgroup has an empty span (zero pieces).  Deferred
+    and undeferred runs must agree bit for bit, also through a second fused deposit."""
+    rs = np.random.RandomState(5)
+    x, y, z = (rs.uniform(-3, 3, n).astype(np.float32) for _ in range(3))
+    th = rs.uniform(0, 6.28, n).astype(np.float32)
+    w = np.zeros(n, dtype=np.float32)
+    hot = np.array([n // 3, n // 3 + 1, n // 3 + 700, n - 1])
+    w[hot] = [1.0, 0.5, 2.0, 0.25]
+    fs = []
+    for deferred in (True, False):
+        f = pfm.DeviceParticleFilterLoc(n, seed=77)
+        f.set_deferred(deferred)
+        f.upload(w, x, y, z, th)
+        f.epoch = 3
+        f.depositVio(1.0, 0.0, 0.0, 0.0, 0.0)
+        f.depositRange(0.5, 0.2, 0.1, 3.0, 0.2)         # ESS ~ 3 of n: resamples
+        f.depositVio(1.2, 0.1, -0.05, 0.02, 0.0)
+        f.depositRange(-1.0, 0.7, 0.0, 2.5, 0.1)        # fused with the resampling above
+        f.depositRssi(0.3, 0.3, 0.0, -60)
+        f.depositRssi(0.0, 0.5, 0.2, -60)
+        fs.append(f)
+    assert np.array_equal(fs[0].branch_log()[0], fs[1].branch_log()[0])
+    assert fs[0].branch_log()[0][0] == 1
+    for c, (u, v) in enumerate(zip(fs[0].download(), fs[1].download())):
+        assert np.array_equal(u, v), f"array {c}"
+
+
+@pytest.mark.parametrize("n", [10000, 50021])
+def test_deferred_sequence_tracks_oracle(pfm, ora, n):
+    """The oracle comparison of test_deposit_sequence_tracks_oracle with the GPU pose read only every fifth
+    deposit, so that most deposits run through the deferred path (last_stats reads the control block only)."""
+    g, o = _pair(pfm, ora, n)
+    k = 0
+    for e in _scene_events(30):
+        for f in (g, o):
+            _deposit_only(f, [e])
+        if e[0] == "vio":
+            continue
+        k += 1
+        if k > 1:
+            gs, os_ = g.last_stats(), o.last_stats()
+            assert int(gs["branch"]) == int(os_["branch"]), f"deposit {k}"
+            assert int(gs["numSpawn"]) == int(os_["numSpawn"])
+            assert abs(gs["ess"] - os_["ess"]) <= 1e-3 * os_["ess"] + (n // 5000) * 1.0, f"deposit {k}"
+        if k % 5 == 0:
+            a, b = g.getTagLoc(), o.getTagLoc()
+            assert np.abs(np.array(a[2:], dtype=np.float64) - np.array(b[2:], dtype=np.float64)).max() <= 1e-4, f"deposit {k}"
+    got, exp = g.download(), o.arrays()
+    wdiff = np.abs(got[0] - exp[0]) > 1e-5 * np.maximum(1.0, np.abs(exp[0]))
+    assert wdiff.sum() <= max(3, n // 5000)
+    for c in range(1, 4):
+        assert np.quantile(np.abs(got[c] - exp[c]), 0.999) <= 1e-4
+
+
 def test_rssi_is_fixed_range(pfm):
     """depositRssi(b, any) == depositRange(b, 1.5, 0.5) (particleFilter.c:213-226): bitwise."""
     a = pfm.DeviceParticleFilterLoc(20000, seed=9)
