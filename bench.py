@@ -36,7 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # 40 B per particle (read w,x,y,z,theta of the ancestors, write them for the offspring) -- see "traffic".
 ALG_BYTES = {"stream": 44, "stream_static": 28, "resample": 40, "resample_stream": 84, "resample_static": 68}
 KERNEL_OF = {"stream": "k_loc_stream<motion,gate>", "stream_static": "k_loc_stream<gate>", "resample": "k_loc_resample",
-             "resample_stream": "k_loc_resample_deposit<motion>", "resample_static": "k_loc_resample_deposit<static>"}
+             "resample_stream": "k_loc_deposit<motion> (resampling side)", "resample_static": "k_loc_deposit<static> (resampling side)"}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -264,14 +264,30 @@ def main():
     if rank == 0:
         names = pfm.DeviceParticleFilterLoc.KINDS
         per = {}
-        for nm in ("stream", "stream_static", "resample", "resample_stream", "resample_static"):
+        # Launch classes.  k_loc_resample after a normalise-only decision exits at once: not counted.  With deferred
+        # resampling a deposit is ONE launch of k_loc_deposit, which resamples-and-deposits or only streams according
+        # to the previous decision (known on the device only); an empty launch takes a few microseconds and a streaming
+        # pass well under the fused one, so the launches of a class are told apart by the device-side branch log
+        # (deposit j of the timed region follows decision j - 1) and, where that does not line up, by duration.
+        classes = {}
+        for nm in ("stream", "stream_static", "resample"):
             sel = ms[kinds == names.index(nm)]
-            # Launches that exit at once are not counted: a resample launch after a normalise-only decision, and, with
-            # deferred resampling, whichever of k_loc_resample_deposit / k_loc_stream the previous decision (known on
-            # the device only) left nothing to do.  An empty launch takes a few microseconds, a real one at least
-            # twenty times that, so a quarter of the longest launch of the class separates them.
             if sel.shape[0]:
                 sel = sel[sel > 0.25 * sel.max()]
+            classes[nm] = sel
+        full_log = pf.branch_log()[0] if world == 1 and not force_sharded else None
+        for nm, fused, plain, phase in (("deposit", "resample_stream", "stream", 0), ("deposit_static", "resample_static", "stream_static", 1)):
+            sel = ms[kinds == names.index(nm)]
+            if not sel.shape[0]:
+                continue
+            prev = None
+            if full_log is not None and full_log.shape[0] >= 2 * K + 1 and sel.shape[0] == K:
+                prev = full_log[-(2 * K + 1):-1][phase::2].astype(bool)      # decision before each deposit of this phase
+            if prev is None:
+                prev = sel > 0.5 * (sel.min() + sel.max())
+            classes[fused] = sel[prev]
+            classes[plain] = np.concatenate([classes.get(plain, sel[:0]), sel[~prev]])
+        for nm, sel in classes.items():
             if sel.shape[0]:
                 avg_ms = float(sel.mean())
                 gbs = ALG_BYTES[nm] * n / (avg_ms * 1e-3) / 1e9

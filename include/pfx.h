@@ -30,8 +30,9 @@ enum { PFX_P_VIO = 1, PFX_P_RSTART = 2, PFX_P_JITTER = 3, PFX_P_SPAWN = 4 };
 enum { PFX_K_STREAM = 0,        /* k_loc_stream with VIO motion (reads and writes all five arrays) */
        PFX_K_DECIDE = 1, PFX_K_RESAMPLE = 2, PFX_K_SPAWN = 3, PFX_K_POSE = 4,
        PFX_K_STREAM_STATIC = 5, /* k_loc_stream without motion (writes the weights only) */
-       PFX_K_RESAMPLE_STREAM = 6,   /* k_loc_resample_deposit: deferred resampling + the next deposit, with motion */
-       PFX_K_RESAMPLE_STATIC = 7,   /* the same without motion */
+       PFX_K_DEPOSIT = 6,       /* k_loc_deposit with motion: the deferred resampling of the previous deposit fused with
+                                   this one, or the streaming pass, as the previous decision (on the device) says */
+       PFX_K_DEPOSIT_STATIC = 7,    /* the same without motion */
        PFX_K_COUNT = 8 };
 
 /* ---- library ---- */

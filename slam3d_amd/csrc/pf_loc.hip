@@ -169,14 +169,14 @@ int launch_set_ctl(pfx_loc* pf, int cur, int branch, float wscale, int keepCur, 
     return check_launch("k_loc_set_ctl");
 }
 
-int launch_stream(pfx_loc* pf, bool motion, bool gate, const Motion& mo, const Gate& ga, bool skipIfResampled = false)
+int launch_stream(pfx_loc* pf, bool motion, bool gate, const Motion& mo, const Gate& ga)
 {
     ProfScope ps(pf, motion ? PFX_K_STREAM : PFX_K_STREAM_STATIC);
     const dim3 grid(pf->numTiles), block(kThreads);
     const RngKey key = key_of(pf);
 #define PF_LAUNCH_STREAM(M, G) \
     hipExtLaunchKernelGGL((k_loc_stream<M, G>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->tileSums, pf->n, \
-                          pf->selfBegin, key, mo, ga, skipIfResampled ? 1 : 0)
+                          pf->selfBegin, key, mo, ga)
     if (motion && gate) PF_LAUNCH_STREAM(true, true);
     else if (motion) PF_LAUNCH_STREAM(true, false);
     else if (gate) PF_LAUNCH_STREAM(false, true);
@@ -218,21 +218,22 @@ int launch_resample(pfx_loc* pf, const RngKey& key, float bx, float by, float bz
     return check_launch("k_loc_resample");
 }
 
-// The deferred resampling of the previous deposit fused with the current one (exits unless that decision was to
-// resample; k_loc_stream, launched next with skipIfResampled, covers the other case).
-int launch_resample_deposit(pfx_loc* pf, bool motion, const Motion& mo, const Gate& ga)
+// One deposit of an unsharded filter while a decision is pending: k_loc_deposit resamples-and-deposits or streams,
+// according to that decision (on the device).
+int launch_deposit(pfx_loc* pf, bool motion, const Motion& mo, const Gate& ga)
 {
-    ProfScope ps(pf, motion ? PFX_K_RESAMPLE_STREAM : PFX_K_RESAMPLE_STATIC);
+    ProfScope ps(pf, motion ? PFX_K_DEPOSIT : PFX_K_DEPOSIT_STATIC);
     const dim3 grid(pf->numTiles), block(kThreads);
     const float* a = pf->deferArg;
-#define PF_LAUNCH_RD(M) \
-    hipExtLaunchKernelGGL((k_loc_resample_deposit<M>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase, \
-                          pf->tileIncl, pf->numTiles, (int)pf->n, pf->deferKey, a[0], a[1], a[2], a[3], a[4], key_of(pf), mo, ga, \
-                          pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles)
-    if (motion) PF_LAUNCH_RD(true);
-    else PF_LAUNCH_RD(false);
-#undef PF_LAUNCH_RD
-    return check_launch("k_loc_resample_deposit");
+    const RespawnShell sh{ a[0], a[1], a[2], a[3], a[4] };
+    const PieceOut out{ pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles };
+#define PF_LAUNCH_DEP(M) \
+    hipExtLaunchKernelGGL((k_loc_deposit<M>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->tileSums, \
+                          pf->chunkBase, pf->tileIncl, pf->numTiles, (int)pf->n, pf->deferKey, sh, key_of(pf), mo, ga, out)
+    if (motion) PF_LAUNCH_DEP(true);
+    else PF_LAUNCH_DEP(false);
+#undef PF_LAUNCH_DEP
+    return check_launch("k_loc_deposit");
 }
 
 // Launch the resample kernel a deposit left pending.  Called by everything that reads or replaces the particles
@@ -482,11 +483,10 @@ extern "C" int pfx_loc_deposit_range(pfx_loc* pf, float bx, float by, float bz, 
         if (launch_decide(pf, range)) return -1;
         return launch_resample(pf, key_of(pf), bx, by, bz, range, stdRange);
     }
-    // Deferred: if the previous decision (still on the device, unknown here) was to resample, the fused kernel does
-    // that and this deposit in one pass and the streaming kernel exits; otherwise the other way round.
+    // Deferred: if the previous decision (still on the device, unknown here) was to resample, k_loc_deposit does
+    // that and this deposit in one pass; otherwise it is the streaming pass.
     const bool open = pf->deferOpen;
-    if (open && launch_resample_deposit(pf, motion, mo, ga)) return -1;
-    if (launch_stream(pf, motion, true, mo, ga, open)) return -1;
+    if (open ? launch_deposit(pf, motion, mo, ga) : launch_stream(pf, motion, true, mo, ga)) return -1;
     if (launch_decide(pf, range, false, open)) return -1;
     pf->deferOpen = true;
     pf->deferKey = key_of(pf);

@@ -72,17 +72,14 @@ constexpr int kMaxChunks = 1024;    // one chunk per thread of k_loc_decide: 102
 __device__ __forceinline__ long long first_offspring_at(double b, double rStart, double rStep, long long n);
 
 // ------------------------------------------------------------------ streaming pass
+// Body of k_loc_stream (and of the normalise-only side of k_loc_deposit).  `red` holds 7 * kThreads doubles of LDS.
 template <bool MOTION, bool GATE>
-__global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const LocCtl* __restrict__ ctl,
-                                                        double* __restrict__ tileSums, long long n, long long idx0,
-                                                        RngKey key, Motion mo, Gate ga, int skipIfResampled)
+__device__ __forceinline__ void stream_tile(const LocBufs& bufs, const LocCtl* __restrict__ ctl,
+                                            double* __restrict__ tileSums, long long n, long long idx0,
+                                            const RngKey& key, const Motion& mo, const Gate& ga, double* red)
 {
     // idx0: global index of local particle 0 (0 unless the filter is one shard of a larger one); the
     // Philox counter uses the global index, so the noise does not depend on how the filter is sharded
-    // skipIfResampled: the previous deposit's resampling was deferred and k_loc_resample_deposit, launched just
-    // before this kernel, has applied this deposit to the offspring as it produced them
-    if (skipIfResampled && ctl->branch == 1) return;
-    __shared__ double red[7 * kThreads];
     const int cur = ctl->cur;
     const float wscale = ctl->wscale;
     float* __restrict__ pw = bufs.a[cur][0];
@@ -149,12 +146,21 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
     block_sum_store<7>(acc, red, tileSums + (size_t)blockIdx.x * kSumsPerTile);
 }
 
+template <bool MOTION, bool GATE>
+__global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const LocCtl* __restrict__ ctl,
+                                                        double* __restrict__ tileSums, long long n, long long idx0,
+                                                        RngKey key, Motion mo, Gate ga)
+{
+    __shared__ double red[7 * kThreads];
+    stream_tile<MOTION, GATE>(bufs, ctl, tileSums, n, idx0, key, mo, ga, red);
+}
+
 // ------------------------------------------------------------------ two-level prefix, level 1
 // Workgroup c sums the seven per-tile sums of its 256 tiles (-> chunkSums[c]) and writes the inclusive
 // prefix of the tile weights inside the chunk (-> tileIncl[t]), made non-decreasing with a max-scan so that
 // rounding in the parallel scan can never order two tile boundaries the wrong way round.
 //
-// pieces != nullptr: the deposit may have been applied by k_loc_resample_deposit (ctl->branch == 1 at this point,
+// pieces != nullptr: the deposit may have been applied by k_loc_deposit (ctl->branch == 1 at this point,
 // i.e. the PREVIOUS decision was to resample).  Then the sums of tile t arrive as pieces, one per source tile that
 // produced offspring inside it, in the consecutive slots headSlot[t] .. tailSlot[t]; they are added in slot order
 // (fixed, so runs are bit-reproducible) and written to tileSums as the streaming kernel would have.
@@ -545,22 +551,34 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
 // Workgroups with an empty span store a zero piece so that the slots between a tile's first and last piece are
 // all written; the workgroups that produce a tile's first and last offspring record those slots.  k_loc_chunks
 // adds the pieces in slot order: deterministic, unlike atomics.
-template <bool MOTION>
-__global__ __launch_bounds__(kThreads) void k_loc_resample_deposit(LocBufs bufs, const LocCtl* __restrict__ ctl,
-                                                                  const double* __restrict__ chunkBase,
-                                                                  const double* __restrict__ tileIncl, int numTiles, int n,
-                                                                  RngKey keyRs, float sbx, float sby, float sbz, float srange,
-                                                                  float sstd, RngKey key, Motion mo, Gate ga,
-                                                                  double* __restrict__ pieceSums, int* __restrict__ headSlot,
-                                                                  int* __restrict__ tailSlot)
-{
-    if (ctl->branch != 1) return;           // the previous deposit only normalised: k_loc_stream does this one
+struct RespawnShell { float bx, by, bz, range, stdRange; };     // pfInit.c:56-66 arguments of the deciding deposit
+struct PieceOut { double* sums; int* headSlot; int* tailSlot; };
 
-    __shared__ double cdf[kTile];
-    __shared__ float4 anc[kTile];
-    __shared__ double park[7 * 64];
-    __shared__ double red[4];
-    __shared__ int span[2];
+struct ResampleDepositLds {
+    double cdf[kTile];
+    float4 anc[kTile];
+    double park[7 * 64];
+    double red[4];
+    int span[2];
+};
+
+template <bool MOTION>
+__device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const LocCtl* __restrict__ ctl,
+                                                      const double* __restrict__ chunkBase,
+                                                      const double* __restrict__ tileIncl, int numTiles, int n,
+                                                      const RngKey& keyRs, const RespawnShell& sh, const RngKey& key,
+                                                      const Motion& mo, const Gate& ga, const PieceOut& out,
+                                                      ResampleDepositLds& L)
+{
+    double* const cdf = L.cdf;
+    float4* const anc = L.anc;
+    double* const park = L.park;
+    double* const red = L.red;
+    int* const span = L.span;
+    double* __restrict__ pieceSums = out.sums;
+    int* __restrict__ headSlot = out.headSlot;
+    int* __restrict__ tailSlot = out.tailSlot;
+    const float sbx = sh.bx, sby = sh.by, sbz = sh.bz, srange = sh.range, sstd = sh.stdRange;
     const int t = blockIdx.x, tid = threadIdx.x;
     const int src = ctl->src, dst = ctl->dst;
     const int tbase = t * kTile;
@@ -713,6 +731,26 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample_deposit(LocBufs bufs,
         }
     }
     store_piece(carryTile, carry);
+}
+
+// One deposit of an unsharded filter with deferred resampling, whichever way the previous decision went (it is
+// known on the device only): after a "resample" decision the offspring are produced and deposited on in one pass,
+// after a "normalise" decision this is k_loc_stream.  One launch instead of two of which one would exit at once
+// (an empty launch of 16 k workgroups plus its gap cost ~8 us of a 170 us deposit).  The two sides share the LDS.
+template <bool MOTION>
+__global__ __launch_bounds__(kThreads) void k_loc_deposit(LocBufs bufs, const LocCtl* __restrict__ ctl,
+                                                         double* __restrict__ tileSums,
+                                                         const double* __restrict__ chunkBase,
+                                                         const double* __restrict__ tileIncl, int numTiles, int n,
+                                                         RngKey keyRs, RespawnShell sh, RngKey key, Motion mo, Gate ga,
+                                                         PieceOut out)
+{
+    static_assert(sizeof(ResampleDepositLds) >= 7 * kThreads * sizeof(double), "stream side needs 7 * kThreads doubles");
+    __shared__ ResampleDepositLds L;
+    if (ctl->branch == 1)
+        resample_deposit_tile<MOTION>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga, out, L);
+    else
+        stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, 0, key, mo, ga, reinterpret_cast<double*>(&L));
 }
 
 // ------------------------------------------------------------------ pose sums after a resampling step

@@ -225,7 +225,7 @@ class DeviceParticleFilterLoc:
     def profile_begin(self, max_records: int = 4096):
         check(self._L.pfx_loc_profile_begin(self._h, int(max_records)), "pfx_loc_profile_begin")
 
-    KINDS = ["stream", "decide", "resample", "spawn", "pose", "stream_static", "resample_stream", "resample_static"]
+    KINDS = ["stream", "decide", "resample", "spawn", "pose", "stream_static", "deposit", "deposit_static"]
 
     def profile_records(self, cap: int = 1 << 16):
         """(kind, ms) per recorded launch, in launch order; kind indexes KINDS."""

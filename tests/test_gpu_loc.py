@@ -496,7 +496,10 @@ def test_config2_range_only_1m(pfm, test1):
     res = R.replay_loc(g, vio, uwb, dep, range_only=True)
     assert res.n_vio == 0 and res.n_range > 900
     prof = g.profile_read()
-    assert prof["stream"]["launches"] == 0 and prof["stream_static"]["launches"] == res.n_range - 1
+    # no launch with motion; every deposit after the spawn is one launch without it (k_loc_stream<static> after the
+    # spawn, k_loc_deposit<static> while a decision is pending)
+    assert prof["stream"]["launches"] == 0 and prof["deposit"]["launches"] == 0
+    assert prof["stream_static"]["launches"] + prof["deposit_static"]["launches"] == res.n_range - 1
     ok, _t, x, y, z, _th = g.getTagLoc()
     assert ok == 1
     assert abs(float(x) + 0.6065) < 0.0235 and abs(float(y) - 3.2254) < 0.0115 and abs(float(z) - 1.9666) < 0.0465

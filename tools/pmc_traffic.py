@@ -31,30 +31,46 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 16000000
     out = {}
-    names = {"stream": "k_loc_stream<true, true>", "stream_static": "k_loc_stream<false, true>", "resample": "k_loc_resample<false>",
-             "resample_stream": "k_loc_resample_deposit<true>", "resample_static": "k_loc_resample_deposit<false>"}
-    for key, pat in names.items():
+
+    def launches(pat):
+        """(read bytes, written bytes) per launch of the kernel whose name contains pat; the two passes replay the
+        same deterministic launch sequence, so launch k of one pass is launch k of the other"""
         fk = [k for k in fetch if pat in k]
         wk = [k for k in write if pat in k]
         if not fk or not wk:
-            continue
-        fv, wv = fetch[fk[0]], write[wk[0]]
-        # drop the launches that exit at once (a resample launch after a normalise-only decision; with deferred
-        # resampling whichever of k_loc_resample_deposit / k_loc_stream had nothing to do); a class that never did
-        # any work in this run is left out
-        fmax, wmax = max(fv), max(wv)
-        if 2.0 * 1024.0 * fmax < 1.0 * n:       # < 1 B read per particle: only empty launches
-            continue
-        fv = [v for v in fv if v > 0.25 * fmax]
-        wv = [v for v in wv if v > 0.25 * wmax]
-        rd = 2.0 * 1024.0 * sum(fv) / len(fv)
-        wr = 1024.0 * sum(wv) / len(wv)
-        out[key] = {"kernel": fk[0].split("(")[0], "launches_fetch_pass": len(fv), "launches_write_pass": len(wv),
-                    "fetch_size_KiB_avg_raw": sum(fv) / len(fv), "write_size_KiB_avg": sum(wv) / len(wv),
-                    "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
-                    "hbm_bytes_per_particle": (rd + wr) / n, "n": n,
-                    "note": "FETCH_SIZE doubled (gfx950 wide-stream correction)" +
-                            ("; reads are float4 per lane like the streaming kernels'" if key.startswith("resample") else "")}
+            return None, []
+        m = min(len(fetch[fk[0]]), len(write[wk[0]]))
+        return fk[0].split("(")[0], [(2.0 * 1024.0 * fetch[fk[0]][i], 1024.0 * write[wk[0]][i]) for i in range(m)]
+
+    def put(key, kernel, sel, note=""):
+        if not sel:
+            return
+        rd = sum(r for r, _ in sel) / len(sel)
+        wr = sum(w for _, w in sel) / len(sel)
+        out[key] = {"kernel": kernel, "launches": len(sel), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                    "hbm_bytes_per_launch": rd + wr, "hbm_bytes_per_particle": (rd + wr) / n, "n": n,
+                    "note": "FETCH_SIZE doubled (gfx950 wide-stream correction)" + note}
+
+    # launches that exit at once (a resample launch after a normalise-only decision) read < 1 B per particle
+    work = lambda ls: [x for x in ls if x[0] > 1.0 * n]
+    k, ls = launches("k_loc_stream<true, true>")
+    put("stream", k, work(ls))
+    k, ls = launches("k_loc_stream<false, true>")
+    put("stream_static", k, work(ls))
+    k, ls = launches("k_loc_resample<false>")
+    put("resample", k, work(ls))
+    # k_loc_deposit is one kernel with two sides (deferred resampling + deposit, or streaming pass only; the previous
+    # decision, on the device, picks).  With motion both sides read 20 B and write 20 B per particle and cannot be
+    # told apart by traffic: reported together.  Without motion the streaming side writes only the weights (4 B).
+    k, ls = launches("k_loc_deposit<true>")
+    put("resample_stream", k, work(ls), "; both sides of k_loc_deposit<motion> (each 20 B read + 20 B written per particle)")
+    if "stream" not in out and "resample_stream" in out:
+        out["stream"] = dict(out["resample_stream"])
+    k, ls = launches("k_loc_deposit<false>")
+    ls = work(ls)
+    put("resample_static", k, [x for x in ls if x[1] > 12.0 * n], "; resampling side of k_loc_deposit<static>")
+    if "stream_static" not in out:
+        put("stream_static", k, [x for x in ls if x[1] <= 12.0 * n], "; streaming side of k_loc_deposit<static>")
     os.makedirs("profiles", exist_ok=True)
     with open("profiles/pmc_traffic.json", "w") as fh:
         json.dump(out, fh, indent=1)
