@@ -45,9 +45,14 @@ def scene(n_steps):
     return _synth.synthetic_scene(n_steps, seed=42)
 
 
+POSE_EVERY_STEP = False     # --pose-every-step: the replay drivers' pattern (a getTagLoc per VIO row); not the headline metric
+
+
 def step(pf, k, bx, truth, rng):
     """one STEP of the workload on any object with the wrapper interface"""
     pf.depositVio(1000.0 + 0.1 * k, float(truth[k, 0]), float(truth[k, 1]), float(truth[k, 2]), 0.0)
+    if POSE_EVERY_STEP:
+        pf.getTagLoc()
     b = k % 8
     pf.depositRange(float(bx[b, 0]), float(bx[b, 1]), float(bx[b, 2]), float(rng[k, 0]), 0.1)
     b = (k + 1) % 8
@@ -177,11 +182,14 @@ def main():
     ap.add_argument("--force-branch", type=int, default=-1, help="-1 reference test, 0 never resample, 1 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="timed region without per-kernel HIP events (no roofline)")
+    ap.add_argument("--pose-every-step", action="store_true", help="also call getTagLoc after every depositVio (driver pattern)")
     ap.add_argument("--undeferred", action="store_true", help="one resample kernel per deposit (pfx_loc_set_deferred(0))")
     ap.add_argument("--workload", default="config3", choices=["config3", "config5"])
     ap.add_argument("--slam-filters", type=int, default=512, help="config5: SLAM tags per GPU")
     ap.add_argument("--slam-bcns", type=int, default=4, help="config5: beacons per tag")
     args = ap.parse_args()
+    global POSE_EVERY_STEP
+    POSE_EVERY_STEP = args.pose_every_step
 
     import torch
     import torch.distributed as dist
@@ -323,6 +331,7 @@ def main():
                                                                        "RCCL all-gather of per-GPU sums per deposit",
                        "force_branch": args.force_branch, "resample_fraction": frac_a,
                        "deferred_resampling": not (args.undeferred or world > 1 or force_sharded),
+                       "pose_every_step": POSE_EVERY_STEP,
                        "rng": "Philox4x32-10 key 123456789", "final_position_error_m": err},
             "roofline": roof, "kernels": per, "cpu_baseline": cpu,
         }

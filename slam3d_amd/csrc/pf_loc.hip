@@ -202,7 +202,7 @@ int launch_decide(pfx_loc* pf, float range, bool localOnly = false, bool pieces 
     return check_launch("k_loc_decide");
 }
 
-int launch_resample(pfx_loc* pf, const RngKey& key, float bx, float by, float bz, float range, float stdRange)
+int launch_resample(pfx_loc* pf, const RngKey& key, float bx, float by, float bz, float range, float stdRange, bool pose = false)
 {
     ProfScope ps(pf, PFX_K_RESAMPLE);
     const dim3 grid(pf->numTiles), block(kThreads);
@@ -210,11 +210,14 @@ int launch_resample(pfx_loc* pf, const RngKey& key, float bx, float by, float bz
     for (int k = 0; k < 4; ++k) st.a[k] = pf->stageSlab ? pf->stageSlab + (size_t)k * pf->stageCap : nullptr;
     st.cap = pf->stageSlab ? (long long)pf->stageCap : 0;
     if (pf->recordAnc)
-        hipExtLaunchKernelGGL((k_loc_resample<true>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase, pf->tileIncl,
-                           pf->anc, pf->numTiles, pf->n, st, key, bx, by, bz, range, stdRange);
+        hipExtLaunchKernelGGL((k_loc_resample<true, false>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase,
+                           pf->tileIncl, pf->anc, pf->numTiles, pf->n, st, key, bx, by, bz, range, stdRange, pf->rsPart);
+    else if (pose && pf->numShards == 1 && !pf->stageSlab)
+        hipExtLaunchKernelGGL((k_loc_resample<false, true>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase,
+                           pf->tileIncl, (int*)nullptr, pf->numTiles, pf->n, st, key, bx, by, bz, range, stdRange, pf->rsPart);
     else
-        hipExtLaunchKernelGGL((k_loc_resample<false>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase, pf->tileIncl,
-                           (int*)nullptr, pf->numTiles, pf->n, st, key, bx, by, bz, range, stdRange);
+        hipExtLaunchKernelGGL((k_loc_resample<false, false>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase,
+                           pf->tileIncl, (int*)nullptr, pf->numTiles, pf->n, st, key, bx, by, bz, range, stdRange, pf->rsPart);
     return check_launch("k_loc_resample");
 }
 
@@ -238,12 +241,12 @@ int launch_deposit(pfx_loc* pf, bool motion, const Motion& mo, const Gate& ga)
 
 // Launch the resample kernel a deposit left pending.  Called by everything that reads or replaces the particles
 // other than the next deposit.
-int materialise(pfx_loc* pf)
-{
+int materialise(pfx_loc* pf, bool pose = false)
+{   // pose: a pose query follows, have the kernel leave the pose sums of the offspring behind
     if (!pf->deferOpen) return 0;
     pf->deferOpen = false;
     const float* a = pf->deferArg;
-    return launch_resample(pf, pf->deferKey, a[0], a[1], a[2], a[3], a[4]);
+    return launch_resample(pf, pf->deferKey, a[0], a[1], a[2], a[3], a[4], pose);
 }
 
 int launch_spawn(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
@@ -508,7 +511,7 @@ extern "C" int pfx_loc_get_tag_loc(pfx_loc* pf, double* t, float* x, float* y, f
     if (!pf->initialized) return 0;
     DeviceGuard g(pf->device);
     if (pf->poseDirty) {
-        if (materialise(pf)) return -1;
+        if (materialise(pf, true)) return -1;
         if (launch_pose(pf)) return -1;
         if (read_ctl(pf)) return -1;
         pf->poseDirty = false;

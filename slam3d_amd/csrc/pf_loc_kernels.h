@@ -396,17 +396,22 @@ struct StagePtrs { float* a[4]; long long cap; };
 // thread produces FOUR CONSECUTIVE offspring, aligned on a 4-element boundary of the destination arrays, so that
 // it stores five float4.  The first and last group of a tile (shared with the neighbouring workgroups) and
 // offspring that go to another shard's staging area take dword stores.
-template <bool RECORD>
-__global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const LocCtl* __restrict__ ctl,
+// POSE (unsharded filters, when the kernel is launched because a pose was asked for): the six pose sums of the
+// offspring (particleFilter.c:263-273 with w = 1) are accumulated on the way and left per workgroup in rsPart, which
+// saves k_loc_pose_tiles its pass over the particles just written.
+template <bool RECORD, bool POSE>
+__global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, LocCtl* __restrict__ ctl,
                                                           const double* __restrict__ chunkBase,
                                                           const double* __restrict__ tileIncl,
                                                           int* __restrict__ ancOut,
                                                           int numTiles, long long n, StagePtrs stage, RngKey key,
-                                                          float bx, float by, float bz, float range, float stdRange)
+                                                          float bx, float by, float bz, float range, float stdRange,
+                                                          double* __restrict__ rsPart)
 {
     if (ctl->branch != 1) return;           // normalise-only step: nothing to do (wave-uniform exit)
 
     __shared__ double cdf[kTile];
+    __shared__ double park[POSE ? 6 * 64 : 1];
     __shared__ float4 anc[kTile];           // x y z theta of the tile's particles
     __shared__ double red[4];
     __shared__ long long span[2];
@@ -453,8 +458,13 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
     anc[tid * 4 + 3] = make_float4(x4.w, y4.w, z4.w, t4.w);
     __syncthreads();
     const long long i0 = span[0], i1 = span[1];
-    if (i0 >= i1) return;
+    if (POSE && t == 0 && tid == 0) ctl->rsValid = 1;   // nobody in this launch reads it; k_loc_pose_tiles then exits
+    if (i0 >= i1) {
+        if (POSE && tid < 6) rsPart[(size_t)t * kRsPerTile + tid] = 0.0;
+        return;
+    }
 
+    double pacc[6] = { 0, 0, 0, 0, 0, 0 };
     const float hTheta = ctl->htheta;
     const long long numSpawn = ctl->numSpawn;
     const long long selfBegin = ctl->selfBegin, selfEnd = ctl->selfEnd, outBegin = ctl->outBegin;
@@ -506,6 +516,11 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
                     const float4 a = anc[jj[m]];
                     spawn_from_other(key, i, a.x, a.y, a.z, a.w, kHxyz, hTheta, ox[m], oy[m], oz[m], ot[m]);
                 }
+                if (POSE) {
+                    float sn, cs;
+                    sincos_bounded(ot[m], sn, cs);
+                    pacc[0] += ox[m]; pacc[1] += oy[m]; pacc[2] += oz[m]; pacc[3] += cs; pacc[4] += sn; pacc[5] += 1.0;
+                }
             }
             if (k0 >= fullB && k0 + 3 < fullE) {
                 *reinterpret_cast<float4*>(dw + k0) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
@@ -533,6 +548,10 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, const L
                 }
             }
         }
+    }
+    if (POSE) {
+        const double r = block_sum_quads<6>(pacc, park);
+        if (tid < 6) rsPart[(size_t)t * kRsPerTile + tid] = r;
     }
 }
 
