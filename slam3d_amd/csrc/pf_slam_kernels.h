@@ -114,13 +114,19 @@ struct SmallLds {
 // Weight pass + decision + in-register resample/normalise of one small filter of n <= 1024 particles held four
 // per thread in `r` (sn/cs = sin/cos of their headings).  (cx,cy,cz) is the respawn centre; index0 the Philox
 // index of particle 0.  Returns the decision (valid in every thread).
+//
+// Two phases, because most rows only normalise: (1) the four sums (pfResample.c:93-106 / :151-164: float products,
+// added in double) go through ONE block reduction in LDS (the CDF area serves as parking space) and thread 0
+// decides; (2) only a resampling filter builds its CDF (block scan), stages the ancestors in LDS and searches.
+// rowSumOut (optional): receives (float) sum w, the factor pfMeasurement.c:148-150 puts on the tag particle.
 __device__ __forceinline__ SmallDecision small_filter_update(Row4& r, const float (&sn)[4], const float (&cs)[4], int j0, int n,
                                                              SmallLds& L, const RngKey& key, uint64_t index0, uint64_t rsIndex,
                                                              float range, float stdRange, bool allowSpawn, bool force,
-                                                             float cx, float cy, float cz, bool lazyNorm = false)
+                                                             float cx, float cy, float cz, bool lazyNorm = false,
+                                                             float* __restrict__ rowSumOut = nullptr)
 {
-    // pfResample.c:93-106 / :151-164: float products, added in double; inclusive CDF by a block scan
-    double acc[4] = { 0, 0, 0, 0 };     // (unused), ss, c, sn
+    const int tid = threadIdx.x;
+    double acc[4] = { 0, 0, 0, 0 };     // s, ss, c, sn
     double a[4];
     double run = 0.0;
 #pragma unroll
@@ -132,21 +138,46 @@ __device__ __forceinline__ SmallDecision small_filter_update(Row4& r, const floa
         acc[2] += wi * cs[k];
         acc[3] += wi * sn[k];
     }
-    double total;
-    const double incl = block_inclusive_scan(run, L.scan, total);
-    const double off = incl - run;
-    const double inf = __builtin_huge_val();
+    acc[0] = run;
+    double* const park = L.cdf;         // 4 * kThreads doubles
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int j = j0 + k;
-        L.cdf[j] = (j < n) ? off + a[k] : inf;
-        L.x[j] = r.x[k]; L.y[j] = r.y[k]; L.z[j] = r.z[k]; L.th[j] = r.th[k];
+    for (int k = 0; k < 4; ++k) park[k * kThreads + tid] = acc[k];
+    __syncthreads();
+    if (tid < 4 * 32) {
+        const int k = tid >> 5, j = tid & 31;
+        const double* p = park + k * kThreads + j;
+        double t = p[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += p[32 * i];
+        park[k * kThreads + j] = t;
     }
-    block_sum<4>(acc, L.red);
-    if (threadIdx.x == 0) L.dec = small_decide(total, acc[1], acc[2], acc[3], n, range, allowSpawn, force, key, rsIndex);
+    __syncthreads();
+    if (tid < 4) {
+        const double* p = park + tid * kThreads;
+        double t = p[0];
+#pragma unroll
+        for (int j = 1; j < 32; ++j) t += p[j];
+        L.red[tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (rowSumOut) *rowSumOut = (float)L.red[0];
+        L.dec = small_decide(L.red[0], L.red[1], L.red[2], L.red[3], n, range, allowSpawn, force, key, rsIndex);
+    }
     __syncthreads();
     const SmallDecision d = L.dec;
-    if (d.resample) {
+    if (d.resample) {                   // uniform over the workgroup
+        double total;
+        const double incl = block_inclusive_scan(run, L.scan, total);
+        const double off = incl - run;
+        const double inf = __builtin_huge_val();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + k;
+            L.cdf[j] = (j < n) ? off + a[k] : inf;
+            L.x[j] = r.x[k]; L.y[j] = r.y[k]; L.z[j] = r.z[k]; L.th[j] = r.th[k];
+        }
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = j0 + k;
@@ -182,15 +213,7 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDim
     const SlamStep st = many ? many[f] : one;
     if (st.mode != 1) return;
     __shared__ SmallLds L;
-    __shared__ double red[4];
-
-    // tag particle i after its VIO motion (stored by k_slam_tag, which runs after every row has read the old one)
-    const size_t ti = (size_t)f * D.tagStride + i;
-    float tx = P.tag[1][ti], ty = P.tag[2][ti], tz = P.tag[3][ti], tth = P.tag[4][ti];
-    if (st.tagMoving) {
-        float sn, cs;
-        motion_particle(RngKey{ st.seed, 0u, st.epoch }, (uint64_t)i, st.tagMo, st.tagMo.stdTheta <= 1e-4f, tx, ty, tz, tth, sn, cs);
-    }
+    __shared__ float tagp[3];
 
     const int c = st.target, n = D.nBcn, j0 = threadIdx.x * 4;
     const size_t base = slam_row_base(D, f, c, i);
@@ -199,6 +222,21 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDim
     const float* const src[5] = { P.bcn[0], P.bcn[1], P.bcn[2], P.bcn[3], P.bcn[4] };
     Row4 r;
     row_load(src, base, j0, n, r);
+
+    // tag particle i after its VIO motion (stored by k_slam_tag, which runs after every row has read the old one):
+    // one lane computes it while the row loads are in flight, the others pick it up from LDS
+    if (threadIdx.x == 0) {
+        const size_t ti = (size_t)f * D.tagStride + i;
+        float px = P.tag[1][ti], py = P.tag[2][ti], pz = P.tag[3][ti], pth = P.tag[4][ti];
+        if (st.tagMoving) {
+            float sn0, cs0;
+            motion_particle(RngKey{ st.seed, 0u, st.epoch }, (uint64_t)i, st.tagMo, st.tagMo.stdTheta <= 1e-4f, px, py, pz, pth, sn0, cs0);
+        }
+        tagp[0] = px; tagp[1] = py; tagp[2] = pz;
+    }
+    __syncthreads();
+    const float tx = tagp[0], ty = tagp[1], tz = tagp[2];
+
     const bool moving = (st.movingMask >> c) & 1u;
     Motion mo{};
     if (moving) mo = bcnMo[(size_t)f * D.maxBcns + c];
@@ -206,7 +244,6 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDim
     const RngKey key{ st.seed, (uint32_t)(c + 1), st.epoch };
     bool thetaChanged = false;
     float sn[4] = { 0, 0, 0, 0 }, cs[4] = { 1, 1, 1, 1 };
-    double sum[1] = { 0.0 };
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int j = j0 + k;
@@ -224,14 +261,12 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDim
         const float dx = tx - r.x[k], dy = ty - r.y[k], dz = tz - r.z[k];
         const float pRange = sqrtf(dx * dx + dy * dy + dz * dz);
         if (fabsf(pRange - st.range) > st.thresh) r.w[k] *= st.minWeight;
-        sum[0] += r.w[k];
     }
-    block_sum<1>(sum, red);
-    if (threadIdx.x == 0) rowSum[(size_t)f * D.nTag + i] = (float)sum[0];      // pfMeasurement.c:148-150: tp->w *= bcnSum
 
-    // _resampleBcn(force = 0) of this row; the normalisation stays pending in rowScale
+    // _resampleBcn(force = 0) of this row; the normalisation stays pending in rowScale.  The row sum that
+    // pfMeasurement.c:148-150 multiplies into the tag particle's weight is the total of the same reduction.
     const SmallDecision d = small_filter_update(r, sn, cs, j0, n, L, key, (uint64_t)i * n, (uint64_t)i, st.range, st.stdRange, true,
-                                                false, tx, ty, tz, true);
+                                                false, tx, ty, tz, true, rowSum + (size_t)f * D.nTag + i);
     row_store1(P.bcn[0], base, j0, n, r.w);
     if (moving || d.resample) {
         row_store1(P.bcn[1], base, j0, n, r.x);
