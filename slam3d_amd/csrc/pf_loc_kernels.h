@@ -1,17 +1,20 @@
 // pf_loc_kernels.h -- HIP kernels of the particleFilterLoc hot path (gfx950, wave64).
 //
-// One deposit (particleFilter.c:178-191) is four launches on the filter's stream, no host sync:
+// One deposit (particleFilter.c:178-191) is three or four launches on the filter's stream, no host sync:
 //   k_loc_stream   VIO motion (pfMeasurement.c:24-49) + range gate (:108-125) + weight/pose sums
 //                  (pfResample.c:41-50, particleFilter.c:263-273) in ONE pass over the SoA arrays;
-//                  per-tile partial sums by wave shuffles + LDS.                       [HBM-bound]
+//                  per-tile sums through LDS.                                          [HBM-bound]
 //   k_loc_chunks   one workgroup per 256 tiles: sums of the tile sums and the in-chunk prefix of the
 //                  tile weights.                                                       [tiny]
-//   k_loc_decide   one workgroup: prefix over chunks (f64), ESS / respawn test, heading bandwidth,
+//   k_loc_decide   one wavefront: prefix over chunks (f64), ESS / respawn test, heading bandwidth,
 //                  rStart from Philox (pfResample.c:51-68).                            [tiny]
 //   k_loc_resample systematic resampling (pfResample.c:70-76): each workgroup rebuilds its tile's
 //                  CDF in LDS, binary-searches the ancestors of its contiguous offspring range,
 //                  gathers, jitters (pfInit.c:68-79), respawns (pfInit.c:56-66) and writes the
 //                  other ping-pong buffer; exits at once on a normalise-only step.      [HBM-bound]
+// Unsharded filters defer the resample kernel: the next deposit launches k_loc_deposit instead of
+// k_loc_stream, which -- according to the pending decision, read on the device -- either produces the
+// offspring and deposits on them in the same pass, or is the streaming pass.          [vector-ALU-bound]
 // The normalisation of a non-resampling step (pfResample.c:80-82, w *= N/s) is not a pass: the factor
 // is kept in the control block and multiplied in by the next reader of w (same product, same rounding).
 //
