@@ -37,6 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 ALG_BYTES = {"stream": 44, "stream_static": 28, "resample": 40, "resample_stream": 84, "resample_static": 68}
 KERNEL_OF = {"stream": "k_loc_stream<motion,gate>", "stream_static": "k_loc_stream<gate>", "resample": "k_loc_resample",
              "resample_stream": "k_loc_deposit<motion> (resampling side)", "resample_static": "k_loc_deposit<static> (resampling side)"}
+# (a sharded filter runs the same two sides in k_loc_deposit_sharded)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -283,7 +284,7 @@ def main():
             if sel.shape[0]:
                 sel = sel[sel > 0.25 * sel.max()]
             classes[nm] = sel
-        full_log = pf.branch_log()[0] if world == 1 and not force_sharded else None
+        full_log = pf.branch_log()[0]       # rank 0's log; a sharded filter takes the same decision on every rank
         for nm, fused, plain, phase in (("deposit", "resample_stream", "stream", 0), ("deposit_static", "resample_static", "stream_static", 1)):
             sel = ms[kinds == names.index(nm)]
             if not sel.shape[0]:
@@ -328,9 +329,10 @@ def main():
                                    "+ depositRssi (2 deposits = 2N particle-updates)",
                        "particles_per_gpu": n, "particles_total": n * world,
                        "parallelism": "single GPU" if world == 1 else f"one filter sharded by particle range over {world} GPUs, "
-                                                                       "RCCL all-gather of per-GPU sums per deposit",
+                                                                       "RCCL all-gather of per-GPU sums per deposit, neighbour "
+                                                                       "send/recv of migrating offspring per resampling",
                        "force_branch": args.force_branch, "resample_fraction": frac_a,
-                       "deferred_resampling": not (args.undeferred or world > 1 or force_sharded),
+                       "deferred_resampling": not args.undeferred or world > 1 or force_sharded,
                        "pose_every_step": POSE_EVERY_STEP,
                        "rng": "Philox4x32-10 key 123456789", "final_position_error_m": err},
             "roofline": roof, "kernels": per, "cpu_baseline": cpu,

@@ -111,27 +111,45 @@ int64_t  pfx_loc_branch_log(pfx_loc* pf, uint8_t* out, int64_t cap, int64_t* tot
  * The caller owns the collectives (slam3d_amd/sharded.py uses torch.distributed = RCCL); these are the local
  * halves of a deposit.  The shard created with pfx_loc_create(n_local, ...) holds the global particles
  * [self_begin, self_begin + n_local) of a filter of n_global; noise is keyed by global index.  Per deposit:
- *   pfx_loc_shard_pass1    VIO commit + streaming pass + local tile prefix; 8 local sums land in device memory
- *                          (returns 1 instead if the filter was uninitialised and has just spawned its particles)
+ *   pfx_loc_shard_begin    VIO commit (returns 1 instead if the filter was uninitialised and has just spawned its
+ *                          particles: nothing else follows)
+ *   pfx_loc_shard_deposit  the O(N) pass, launched WITHOUT looking at the previous deposit's decision: after a
+ *                          "resample" the kernel produces the offspring of the local ancestors and deposits on them in
+ *                          the same pass (those whose index is outside the shard's own range are staged as
+ *                          (x, y, z, theta) records, first those below the range, then those above it); after a
+ *                          "normalise" it is the streaming pass
+ *   pfx_loc_shard_plan     the previous deposit's decision (it landed in pinned host memory while the kernel above was
+ *                          launched): branch and F[g] = first global offspring index produced by shard g
+ *                          (F[num_shards] = n_global).  Fails if the staging area is too small.
+ *   after a "resample":
+ *     shipping             the caller sends each neighbour its slice of the staging area into that shard's landing area
+ *                          (record k of the landing area = local element k for k < lo, else hi + (k - lo), where
+ *                          [lo, hi) are the elements the shard produced itself)
+ *     pfx_loc_shard_land(1, lo, hi)  the received records are unpacked into the arrays and deposited on
+ *     pfx_loc_shard_finish(1, lo, hi)  local tile prefix from the pieces; the 8 local sums land in device memory
+ *   after a "normalise":   pfx_loc_shard_finish(0, 0, 0)
  *   all-gather             of pfx_loc_shard_local_ptr (8 doubles) into pfx_loc_shard_all_ptr (rank-major), by the caller
- *   pfx_loc_shard_decide_resample  the reference's ESS / respawn decision on the GLOBAL totals, identical on every
- *                          rank, and right behind it on the stream the resampling of the local ancestors (a no-op on a
- *                          normalise-only step): offspring with index inside the shard's own range go to the other
- *                          buffer, the rest to the staging arrays (first those below the range, then those above).
- *                          Returns without waiting.
- *   pfx_loc_shard_plan     waits for the decision only (it lands in pinned host memory): branch and F[g] = first
- *                          global offspring index produced by shard g (F[num_shards] = n_global).  On a resampling
- *                          step the caller then ships the staged offspring into the owners' current arrays and sets
- *                          their weights with pfx_loc_shard_fill_w.  Fails if the staging area was too small. */
+ *   pfx_loc_shard_decide   the reference's ESS / respawn decision on the GLOBAL totals, identical on every rank;
+ *                          returns without waiting.  A "resample" is acted on by the next pfx_loc_shard_deposit.
+ * Before anything reads the particles (pose query, download): pfx_loc_shard_plan, and if it says "resample"
+ * pfx_loc_shard_produce (the plain resampling), shipping, pfx_loc_shard_land(0, lo, hi). */
 int      pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64_t n_global, int64_t self_begin, int64_t stage_capacity);
-int      pfx_loc_shard_pass1(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);
+int      pfx_loc_shard_begin(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);
+int      pfx_loc_shard_deposit(pfx_loc* pf);
 void*    pfx_loc_shard_local_ptr(pfx_loc* pf);      /* device address: s ss csum ssum wx wy wz 0 */
 void*    pfx_loc_shard_all_ptr(pfx_loc* pf);        /* device address: 16 x 8 doubles */
-int      pfx_loc_shard_decide_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);
+int      pfx_loc_shard_decide(pfx_loc* pf);
 int      pfx_loc_shard_plan(pfx_loc* pf, int* out_branch, int64_t* out_F);
-int      pfx_loc_shard_ptrs_both(pfx_loc* pf, void* d_stage[4], void* d_buf0[5], void* d_buf1[5]);  /* no synchronisation */
+/* 0: nothing outstanding; 1: a decision has been launched and neither looked at nor acted on; 2: it was "resample"
+ * and its offspring have not been produced */
+int      pfx_loc_shard_pending(const pfx_loc* pf);
+int      pfx_loc_shard_produce(pfx_loc* pf);
+int      pfx_loc_shard_land(pfx_loc* pf, int deposit, int64_t lo, int64_t hi);
+int      pfx_loc_shard_finish(pfx_loc* pf, int pieces, int64_t lo, int64_t hi);
+/* device pointers: send and landing halves of the staging area (stage_capacity records of 4 floats each) and both
+ * particle buffers (w,x,y,z,theta); no synchronisation */
+int      pfx_loc_shard_ptrs_both(pfx_loc* pf, void** d_stage_send, void** d_stage_land, void* d_buf0[5], void* d_buf1[5]);
 int      pfx_loc_shard_cur(const pfx_loc* pf);     /* which of the two buffers is current (after pfx_loc_shard_plan) */
-int      pfx_loc_shard_fill_w(pfx_loc* pf, int cur, int64_t begin, int64_t count);
 int      pfx_loc_shard_pose_sums(pfx_loc* pf, double out[6]);   /* local sums of w, wx, wy, wz, w cos, w sin */
 /* particleFilter.c:274-290 on caller-supplied (e.g. all-reduced) pose sums; 1 ok, 0 not initialised */
 int      pfx_loc_pose_from_sums(pfx_loc* pf, const double sums[6], double* t, float* x, float* y, float* z, float* theta);

@@ -73,14 +73,18 @@ def lib() -> C.CDLL:
     sig("pfx_loc_profile_records", i64, vp, vp, vp, i64)
     sig("pfx_loc_branch_log", i64, vp, vp, i64, C.POINTER(i64))
     sig("pfx_loc_shard_config", i, vp, i, i, i64, i64, i64)
-    sig("pfx_loc_shard_pass1", i, vp, f, f, f, f, f)
+    sig("pfx_loc_shard_begin", i, vp, f, f, f, f, f)
+    sig("pfx_loc_shard_deposit", i, vp)
     sig("pfx_loc_shard_local_ptr", vp, vp)
     sig("pfx_loc_shard_all_ptr", vp, vp)
-    sig("pfx_loc_shard_decide_resample", i, vp, f, f, f, f, f)
+    sig("pfx_loc_shard_decide", i, vp)
     sig("pfx_loc_shard_plan", i, vp, C.POINTER(i), C.POINTER(i64))
-    sig("pfx_loc_shard_ptrs_both", i, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
+    sig("pfx_loc_shard_pending", i, vp)
+    sig("pfx_loc_shard_produce", i, vp)
+    sig("pfx_loc_shard_land", i, vp, i, i64, i64)
+    sig("pfx_loc_shard_finish", i, vp, i, i64, i64)
+    sig("pfx_loc_shard_ptrs_both", i, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp))
     sig("pfx_loc_shard_cur", i, vp)
-    sig("pfx_loc_shard_fill_w", i, vp, i, i64, i64)
     sig("pfx_loc_shard_pose_sums", i, vp, pd_)
     sig("pfx_loc_pose_from_sums", i, vp, pd_, pd_, pf_, pf_, pf_, pf_)
     sig("pfx_loc_of", vp, vp)

@@ -115,11 +115,21 @@ struct pfx_loc {
     int rank = 0, numShards = 1;
     long long nGlobal = 0, selfBegin = 0;
     size_t stageCap = 0;
-    float* stageSlab = nullptr;     // 4 arrays of stageCap floats
+    float* stageSlab = nullptr;     // 2 * stageCap records of 4 floats: to send, then landing
     double* dAll = nullptr;         // kMaxShards * 8 gathered sums
     ShardPlan* hostPlan = nullptr;  // pinned, device-mapped: the decision kernel writes it, the host polls it
     ShardPlan* dPlanMapped = nullptr;   // device address of hostPlan
     int shardCur = 0;               // host-side track of the current buffer (sharded filters only)
+    // 0: nothing pending; 1: a global decision has been launched, not looked at, not acted on; 2: it was "resample"
+    // and its offspring are not produced yet
+    int shardPending = 0;
+    bool planRead = false;          // pfx_loc_shard_plan has been called for the last decision
+    unsigned long long planSeq = 0; // the deposit (epoch) of the last decision launched
+    bool shMotion = false;          // the deposit begun by pfx_loc_shard_begin
+    Motion shMo{};
+    Gate shGa{};
+    float shArg[5] = { 0, 0, 0, 0, 0 };
+    double* extraSums = nullptr;    // numTiles * kSumsPerTile: sums of the received elements of each tile (k_loc_land)
     // profiling
     std::vector<ProfRec> prof;
     size_t profUsed = 0;
@@ -185,11 +195,12 @@ int launch_stream(pfx_loc* pf, bool motion, bool gate, const Motion& mo, const G
     return check_launch("k_loc_stream");
 }
 
-int launch_decide(pfx_loc* pf, float range, bool localOnly = false, bool pieces = false)
-{
+int launch_decide(pfx_loc* pf, float range, bool localOnly = false, bool pieces = false, int lo = 0, int hi = -1)
+{   // pieces: the per-tile sums come as pieces of the elements [lo, hi) produced here (+ sums of received elements)
     ProfScope ps(pf, PFX_K_DECIDE);
-    TilePieces tp{ nullptr, nullptr, nullptr };
-    if (pieces) tp = TilePieces{ pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles };
+    TilePieces tp{ nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
+    if (pieces)
+        tp = TilePieces{ pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles, pf->extraSums, lo, hi < 0 ? (int)pf->n : hi, (int)pf->n };
     hipExtLaunchKernelGGL(k_loc_chunks, dim3(pf->numChunks), dim3(kChunkTiles), 0, pf->stream, ps.a(), nullptr, 0, pf->tileSums,
                           pf->tileIncl, pf->chunkSums, pf->numTiles, pf->ctl, tp);
     if (check_launch("k_loc_chunks")) return -1;
@@ -207,7 +218,7 @@ int launch_resample(pfx_loc* pf, const RngKey& key, float bx, float by, float bz
     ProfScope ps(pf, PFX_K_RESAMPLE);
     const dim3 grid(pf->numTiles), block(kThreads);
     StagePtrs st{};
-    for (int k = 0; k < 4; ++k) st.a[k] = pf->stageSlab ? pf->stageSlab + (size_t)k * pf->stageCap : nullptr;
+    st.rec = reinterpret_cast<float4*>(pf->stageSlab);
     st.cap = pf->stageSlab ? (long long)pf->stageCap : 0;
     if (pf->recordAnc)
         hipExtLaunchKernelGGL((k_loc_resample<true, false>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase,
@@ -306,6 +317,7 @@ void free_device(pfx_loc* pf)
     if (pf->ctl) hipFree(pf->ctl);
     if (pf->hostCtl) hipHostFree(pf->hostCtl);
     if (pf->stageSlab) hipFree(pf->stageSlab);
+    if (pf->extraSums) hipFree(pf->extraSums);
     if (pf->dAll) hipFree(pf->dAll);
     if (pf->hostPlan) hipHostFree(pf->hostPlan);
     for (auto& r : pf->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -545,6 +557,7 @@ extern "C" int pfx_loc_download(pfx_loc* pf, float* w, float* x, float* y, float
 {
     clear_error();
     if (n != pf->n) { set_error("pfx_loc_download: n=%lld but the filter holds %lld", (long long)n, pf->n); return -2; }
+    if (pf->shardPending) { set_error("pfx_loc_download: a sharded resampling is pending (pfx_loc_shard_produce / land first)"); return -2; }
     DeviceGuard g(pf->device);
     if (materialise(pf)) return -1;
     if (read_ctl(pf)) return -1;
@@ -683,12 +696,17 @@ extern "C" int pfx_resample_indices_f64(const double* cdf, int64_t n, double rSt
 
 // ------------------------------------------------------------------ one filter sharded over several GPUs
 // The host side (slam3d_amd/sharded.py) owns the collectives; these entry points are the local halves of a
-// deposit.  Sequence per deposit on every rank:
-//   pfx_loc_shard_pass1   stream kernel + local prefix; the 8 local sums land in device memory
-//   (all-gather of the 8 doubles of every rank into pfx_loc_shard_all_ptr, by the caller, e.g. RCCL)
-//   pfx_loc_shard_decide  the global decision on the gathered sums, identical on every rank; returns the plan
-//   pfx_loc_shard_resample (if the plan says so) offspring of the local particles; those that belong to another
-//                         shard's index range are staged, the caller ships them (P2P) into the peers' arrays
+// deposit.  Sequence per deposit on every rank (include/pfx.h has the long form):
+//   pfx_loc_shard_begin                      VIO commit; spawns on the first range
+//   no resampling pending:  pfx_loc_shard_stream            streaming pass + local prefix
+//   resampling pending:     pfx_loc_shard_produce(1)        offspring of the local ancestors, deposited on in the same
+//                                                           pass; the foreign ones staged as records
+//                           (records shipped to the owners' landing areas by the caller, e.g. RCCL send/recv)
+//                           pfx_loc_shard_land(1, lo, hi)   received records unpacked and deposited on
+//                           pfx_loc_shard_finish(lo, hi)    local prefix from the pieces
+//   (all-gather of the 8 local sums of every rank into pfx_loc_shard_all_ptr, by the caller)
+//   pfx_loc_shard_decide + pfx_loc_shard_plan  the global decision, identical on every rank; a "resample" stays pending
+// A pending resampling is materialised without a deposit (pose query, download) by produce(0) + shipping + land(0).
 extern "C" int pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64_t n_global, int64_t self_begin,
                                     int64_t stage_capacity)
 {
@@ -707,66 +725,117 @@ extern "C" int pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64
         memset(pf->hostPlan, 0, sizeof(ShardPlan));
         pf->hostPlan->seq = ~0ull;
         PF_HIP_OK(hipHostGetDevicePointer((void**)&pf->dPlanMapped, pf->hostPlan, 0));
+        PF_HIP_OK(hipMalloc((void**)&pf->extraSums, (size_t)pf->numTiles * kSumsPerTile * sizeof(double)));
+        PF_HIP_OK(hipMemsetAsync(pf->extraSums, 0, (size_t)pf->numTiles * kSumsPerTile * sizeof(double), pf->stream));
     }
     if (stage_capacity > 0 && (size_t)stage_capacity != pf->stageCap) {
         if (pf->stageSlab) { PF_HIP_OK(hipStreamSynchronize(pf->stream)); hipFree(pf->stageSlab); pf->stageSlab = nullptr; }
         pf->stageCap = (size_t)stage_capacity;
-        PF_HIP_OK(hipMalloc((void**)&pf->stageSlab, pf->stageCap * 4 * sizeof(float)));
+        // records (x, y, z, theta): stageCap to send, stageCap to land what the neighbours send
+        PF_HIP_OK(hipMalloc((void**)&pf->stageSlab, pf->stageCap * 2 * sizeof(float4)));
     }
+    pf->shardPending = 0;
     return 0;
 }
 
-// returns 1 if the filter was not initialised and has now been spawned (no decision follows), 0 otherwise
-extern "C" int pfx_loc_shard_pass1(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+namespace {
+StagePtrs stage_of(pfx_loc* pf)
+{
+    StagePtrs st{};
+    st.rec = reinterpret_cast<float4*>(pf->stageSlab);
+    st.cap = pf->stageSlab ? (long long)pf->stageCap : 0;
+    return st;
+}
+float4* landing_of(pfx_loc* pf) { return reinterpret_cast<float4*>(pf->stageSlab) + pf->stageCap; }
+int shard_ready(pfx_loc* pf, const char* fn)
+{
+    if (!pf->dAll || !pf->stageSlab) { set_error("%s: call pfx_loc_shard_config first", fn); return -2; }
+    return 0;
+}
+}  // namespace
+
+// returns 1 if the filter was not initialised and has now been spawned (nothing else follows), 0 otherwise
+extern "C" int pfx_loc_shard_begin(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
 {
     clear_error();
+    if (shard_ready(pf, "pfx_loc_shard_begin")) return -2;
     DeviceGuard g(pf->device);
-    if (materialise(pf)) return -1;
     float d[5];
     pf->epoch++;
     vio_commit(pf->vio, d);
     pf->poseDirty = true;
+    pf->shMotion = !is_zero_motion(d);
+    pf->shMo = motion_of(d);
+    pf->shGa = gate_of(bx, by, bz, range, stdRange);
+    pf->shArg[0] = bx; pf->shArg[1] = by; pf->shArg[2] = bz; pf->shArg[3] = range; pf->shArg[4] = stdRange;
     if (!pf->initialized) {
         if (launch_spawn(pf, bx, by, bz, range, stdRange)) return -1;
         pf->initialized = true;
         pf->shardCur = 0;
+        pf->shardPending = 0;
         return 1;
     }
-    if (launch_stream(pf, !is_zero_motion(d), true, motion_of(d), gate_of(bx, by, bz, range, stdRange))) return -1;
-    if (launch_decide(pf, range, true)) return -1;
     return 0;
+}
+
+// The O(N) pass of the deposit begun by pfx_loc_shard_begin.  If a global decision is outstanding (whether or not
+// the caller has looked at it), one kernel does what it calls for on the device: after "resample" the offspring of
+// the local ancestors are produced and deposited on in the same pass (foreign ones staged as records), after
+// "normalise" it is the streaming pass.  Otherwise (first deposit after the spawn, or after a settle): streaming pass.
+extern "C" int pfx_loc_shard_deposit(pfx_loc* pf)
+{
+    clear_error();
+    if (shard_ready(pf, "pfx_loc_shard_deposit")) return -2;
+    DeviceGuard g(pf->device);
+    if (pf->shardPending == 0) return launch_stream(pf, pf->shMotion, true, pf->shMo, pf->shGa);
+    pf->shardPending = 0;
+    ProfScope ps(pf, pf->shMotion ? PFX_K_DEPOSIT : PFX_K_DEPOSIT_STATIC);
+    const dim3 grid(pf->numTiles), block(kThreads);
+    const float* a = pf->deferArg;
+    const RespawnShell sh{ a[0], a[1], a[2], a[3], a[4] };
+    const PieceOut out{ pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles };
+#define PF_LAUNCH_DS(M) \
+    hipExtLaunchKernelGGL((k_loc_deposit_sharded<M>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->tileSums, \
+                          pf->chunkBase, pf->tileIncl, pf->numTiles, (int)pf->n, (long long)pf->selfBegin, pf->deferKey, sh, key_of(pf), \
+                          pf->shMo, pf->shGa, out, stage_of(pf))
+    if (pf->shMotion) PF_LAUNCH_DS(true);
+    else PF_LAUNCH_DS(false);
+#undef PF_LAUNCH_DS
+    return check_launch("k_loc_deposit_sharded");
 }
 
 extern "C" void* pfx_loc_shard_local_ptr(pfx_loc* pf) { return (void*)pf->ctl->local; }   // device address, 8 doubles
 extern "C" void* pfx_loc_shard_all_ptr(pfx_loc* pf) { return (void*)pf->dAll; }           // device, kMaxShards*8 doubles
 
-// The global decision and, in the same breath, the local resampling it may call for -- nothing waits for the host:
-// k_loc_shard_decide writes the plan into pinned host memory (sequence number last) and k_loc_resample follows on
-// the stream, exiting at once on a normalise-only step.
-extern "C" int pfx_loc_shard_decide_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+// The global decision -- nothing waits for the host: k_loc_shard_decide writes the plan into pinned host memory
+// (sequence number last), pfx_loc_shard_plan polls it.
+extern "C" int pfx_loc_shard_decide(pfx_loc* pf)
 {
     clear_error();
-    if (!pf->dAll) { set_error("pfx_loc_shard_decide_resample: call pfx_loc_shard_config first"); return -2; }
+    if (shard_ready(pf, "pfx_loc_shard_decide")) return -2;
     DeviceGuard g(pf->device);
-    {
-        ProfScope ps(pf, PFX_K_DECIDE);
-        hipExtLaunchKernelGGL(k_loc_shard_decide, dim3(1), dim3(64), 0, pf->stream, ps.a(), ps.b(), 0, pf->ctl, pf->dAll, pf->numShards,
-                              pf->rank, pf->nGlobal, pf->selfBegin, pf->selfBegin + pf->n, range, key_of(pf), pf->force, pf->branchLog,
-                              pf->dPlanMapped, (unsigned long long)pf->epoch);
-        if (check_launch("k_loc_shard_decide")) return -1;
-    }
-    return launch_resample(pf, key_of(pf), bx, by, bz, range, stdRange);
+    ProfScope ps(pf, PFX_K_DECIDE);
+    hipExtLaunchKernelGGL(k_loc_shard_decide, dim3(1), dim3(64), 0, pf->stream, ps.a(), ps.b(), 0, pf->ctl, pf->dAll, pf->numShards,
+                          pf->rank, pf->nGlobal, pf->selfBegin, pf->selfBegin + pf->n, pf->shArg[3], key_of(pf), pf->force, pf->branchLog,
+                          pf->dPlanMapped, (unsigned long long)pf->epoch);
+    if (check_launch("k_loc_shard_decide")) return -1;
+    pf->deferKey = key_of(pf);                  // what the resampling will need if the decision calls for one
+    for (int k = 0; k < 5; ++k) pf->deferArg[k] = pf->shArg[k];
+    pf->shardPending = 1;
+    pf->planRead = false;
+    pf->planSeq = (unsigned long long)pf->epoch;
+    return 0;
 }
 
 // Wait for the plan of the current deposit (polls the pinned copy; falls back to a stream synchronisation).
 // out_F: num_shards + 1 global offspring boundaries (meaningful when *out_branch == 1).  Fails if the offspring
-// that belong to other shards did not fit the staging area (the kernel dropped the excess).
+// that belong to other shards will not fit the staging area.  A "resample" decision leaves the resampling pending.
 extern "C" int pfx_loc_shard_plan(pfx_loc* pf, int* out_branch, int64_t* out_F)
 {
     clear_error();
     if (!pf->hostPlan) { set_error("pfx_loc_shard_plan: call pfx_loc_shard_config first"); return -2; }
     DeviceGuard g(pf->device);
-    const unsigned long long want = (unsigned long long)pf->epoch;
+    const unsigned long long want = pf->planSeq;    // the caller may already have begun the next deposit
     const auto t0 = std::chrono::steady_clock::now();
     long spins = 0;
     while (__atomic_load_n(&pf->hostPlan->seq, __ATOMIC_ACQUIRE) != want) {
@@ -783,55 +852,95 @@ extern "C" int pfx_loc_shard_plan(pfx_loc* pf, int* out_branch, int64_t* out_F)
         const long long sb = pf->selfBegin, se = pf->selfBegin + pf->n;
         const long long below = sb > ob ? (sb < oe ? sb : oe) - ob : 0;
         const long long above = oe > se ? oe - (se > ob ? se : ob) : 0;
-        if ((size_t)(below + above) > pf->stageCap) {
-            set_error("pfx_loc_shard_plan: %lld offspring belong to other shards but the staging area holds %zu "
-                      "(shard imbalance beyond the configured slack)", below + above, pf->stageCap);
+        const long long ownLo = ob > sb ? ob : sb, ownHi = oe < se ? oe : se;
+        const long long received = pf->n - (ownHi > ownLo ? ownHi - ownLo : 0);
+        if ((size_t)(below + above) > pf->stageCap || (size_t)received > pf->stageCap) {
+            set_error("pfx_loc_shard_plan: %lld offspring leave and %lld arrive but the staging area holds %zu "
+                      "(shard imbalance beyond the configured slack)", below + above, received, pf->stageCap);
             return -3;
         }
-        pf->shardCur ^= 1;
+        if (!pf->planRead) pf->shardCur ^= 1;
+        if (pf->shardPending == 1) pf->shardPending = 2;
+    } else if (pf->shardPending == 1) {
+        pf->shardPending = 0;
     }
+    pf->planRead = true;
     return 0;
 }
 
-// device pointers: the staging arrays (x,y,z,theta) and BOTH particle buffers (w,x,y,z,theta); no synchronisation.
-// pfx_loc_shard_cur tells which buffer is current after the last pfx_loc_shard_plan (tracked on the host).
-extern "C" int pfx_loc_shard_ptrs_both(pfx_loc* pf, void* stage[4], void* buf0[5], void* buf1[5])
+// A pending resampling produced WITHOUT a deposit (a pose query or a download comes first): k_loc_resample; foreign
+// offspring go to the send half of the staging area as records.  Call pfx_loc_shard_plan first: only a "resample"
+// decision leaves anything to produce.
+extern "C" int pfx_loc_shard_produce(pfx_loc* pf)
 {
     clear_error();
-    for (int k = 0; k < 4; ++k) stage[k] = pf->stageSlab ? (void*)(pf->stageSlab + (size_t)k * pf->stageCap) : nullptr;
+    if (shard_ready(pf, "pfx_loc_shard_produce")) return -2;
+    if (pf->shardPending != 2) { set_error("pfx_loc_shard_produce: no resampling is pending (read the plan first)"); return -2; }
+    DeviceGuard g(pf->device);
+    pf->shardPending = 0;
+    const float* a = pf->deferArg;
+    return launch_resample(pf, pf->deferKey, a[0], a[1], a[2], a[3], a[4]);
+}
+
+// The records that arrived in the landing half of the staging area: record k belongs to local element k (k < lo) or
+// hi + (k - lo); [lo, hi) are the elements this shard produced itself.  Unpacked into the current arrays with w = 1;
+// deposit = 1: deposited on as well (after pfx_loc_shard_produce(1)).
+extern "C" int pfx_loc_shard_land(pfx_loc* pf, int deposit, int64_t lo, int64_t hi)
+{
+    clear_error();
+    if (shard_ready(pf, "pfx_loc_shard_land")) return -2;
+    if (lo < 0 || hi < lo || hi > pf->n) { set_error("pfx_loc_shard_land: [%lld, %lld) is not a range of the shard", (long long)lo, (long long)hi); return -2; }
+    if ((size_t)(lo + (pf->n - hi)) > pf->stageCap) { set_error("pfx_loc_shard_land: more records than the landing area holds"); return -2; }
+    if (lo == 0 && hi == pf->n) return 0;
+    DeviceGuard g(pf->device);
+    const int tilesBelow = (int)((lo + kTile - 1) / kTile);
+    int firstAbove = (int)(hi / kTile);
+    if (firstAbove < tilesBelow) firstAbove = tilesBelow;
+    const int tilesAbove = hi < pf->n ? pf->numTiles - firstAbove : 0;
+    const int grid = tilesBelow + (tilesAbove > 0 ? tilesAbove : 0);
+    if (grid <= 0) return 0;
+#define PF_LAUNCH_LAND(M, D) \
+    hipLaunchKernelGGL((k_loc_land<M, D>), dim3(grid), dim3(kThreads), 0, pf->stream, pf->bufs, pf->ctl, landing_of(pf), (int)lo, (int)hi, \
+                       (int)pf->n, tilesBelow, firstAbove, (long long)pf->selfBegin, key_of(pf), pf->shMo, pf->shGa, pf->extraSums)
+    if (!deposit) PF_LAUNCH_LAND(false, false);
+    else if (pf->shMotion) PF_LAUNCH_LAND(true, true);
+    else PF_LAUNCH_LAND(false, true);
+#undef PF_LAUNCH_LAND
+    return check_launch("k_loc_land");
+}
+
+// The local prefix and the 8 local sums for the all-gather.  pieces = 0: after a streaming pass.  pieces = 1: after a
+// resampling deposit, the per-tile sums come from the pieces of the produced elements [lo, hi) and the sums of the
+// received ones (pfx_loc_shard_land(1, ...)).
+extern "C" int pfx_loc_shard_finish(pfx_loc* pf, int pieces, int64_t lo, int64_t hi)
+{
+    clear_error();
+    if (shard_ready(pf, "pfx_loc_shard_finish")) return -2;
+    if (!pieces) return launch_decide(pf, pf->shArg[3], true);
+    if (lo < 0 || hi < lo || hi > pf->n) { set_error("pfx_loc_shard_finish: [%lld, %lld) is not a range of the shard", (long long)lo, (long long)hi); return -2; }
+    DeviceGuard g(pf->device);
+    return launch_decide(pf, pf->shArg[3], true, true, (int)lo, (int)hi);
+}
+
+// device pointers: the send and landing halves of the staging area (records of 4 floats) and BOTH particle buffers
+// (w,x,y,z,theta); no synchronisation.  pfx_loc_shard_cur tells which buffer is current after the last
+// pfx_loc_shard_plan (tracked on the host).
+extern "C" int pfx_loc_shard_ptrs_both(pfx_loc* pf, void** stage_send, void** stage_land, void* buf0[5], void* buf1[5])
+{
+    clear_error();
+    *stage_send = pf->stageSlab ? (void*)pf->stageSlab : nullptr;
+    *stage_land = pf->stageSlab ? (void*)landing_of(pf) : nullptr;
     for (int k = 0; k < 5; ++k) { buf0[k] = pf->bufs.a[0][k]; buf1[k] = pf->bufs.a[1][k]; }
     return 0;
 }
 extern "C" int pfx_loc_shard_cur(const pfx_loc* pf) { return pf->shardCur; }
+extern "C" int pfx_loc_shard_pending(const pfx_loc* pf) { return pf->shardPending; }
 
-// device pointers: the staging arrays (x,y,z,theta) and the CURRENT particle arrays (w,x,y,z,theta).  After a
-// resampling decision "current" is the buffer the offspring are written to.  Uses the host copy of the plan.
-extern "C" int pfx_loc_shard_ptrs(pfx_loc* pf, void* stage[4], void* current[5])
-{
-    clear_error();
-    DeviceGuard g(pf->device);
-    if (read_ctl(pf)) return -1;
-    for (int k = 0; k < 4; ++k) stage[k] = pf->stageSlab ? (void*)(pf->stageSlab + (size_t)k * pf->stageCap) : nullptr;
-    for (int k = 0; k < 5; ++k) current[k] = pf->bufs.a[pf->hostCtl->cur][k];
-    return 0;
-}
-
-// w[begin, begin+count) = 1 in the current buffer: the weights of offspring received from other shards
-extern "C" int pfx_loc_shard_fill_w(pfx_loc* pf, int cur, int64_t begin, int64_t count)
-{
-    clear_error();
-    if (count <= 0) return 0;
-    if (begin < 0 || begin + count > pf->n || cur < 0 || cur > 1) { set_error("pfx_loc_shard_fill_w: range outside the shard"); return -2; }
-    DeviceGuard g(pf->device);
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, pf->stream, pf->bufs.a[cur][0] + begin, 1.0f,
-                       (long long)count);
-    return check_launch("k_fill");
-}
-
-// local pose sums {sum w, w x, w y, w z, w cos, w sin} of the particles this shard produced / holds
+// local pose sums {sum w, w x, w y, w z, w cos, w sin} of the particles this shard holds
 extern "C" int pfx_loc_shard_pose_sums(pfx_loc* pf, double out[6])
 {
     clear_error();
+    if (pf->shardPending) { set_error("pfx_loc_shard_pose_sums: a resampling is pending (produce / land first)"); return -2; }
     DeviceGuard g(pf->device);
     if (materialise(pf)) return -1;
     if (launch_pose(pf)) return -1;

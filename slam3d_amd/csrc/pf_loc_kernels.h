@@ -167,7 +167,10 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
 // i.e. the PREVIOUS decision was to resample).  Then the sums of tile t arrive as pieces, one per source tile that
 // produced offspring inside it, in the consecutive slots headSlot[t] .. tailSlot[t]; they are added in slot order
 // (fixed, so runs are bit-reproducible) and written to tileSums as the streaming kernel would have.
-struct TilePieces { const double* sums; const int* headSlot; const int* tailSlot; };
+//
+// Sharded filters: only the local elements [lo, hi) were produced here (pieces); the elements [0, lo) and [hi, n)
+// arrived from the neighbouring shards and k_loc_land summed them per tile into `extra`.
+struct TilePieces { const double* sums; const int* headSlot; const int* tailSlot; const double* extra; int lo, hi, n; };
 
 __global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(double* __restrict__ tileSums, double* __restrict__ tileIncl,
                                                            double* __restrict__ chunkSums, int numTiles,
@@ -180,11 +183,19 @@ __global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(double* __restrict__
     if (t < numTiles) {
         double* p = tileSums + (size_t)t * kSumsPerTile;
         if (pieces.sums != nullptr && ctl->branch == 1) {
-            int h = pieces.headSlot[t], e = pieces.tailSlot[t];
-            h = h < 0 ? 0 : h;
-            e = e >= 2 * numTiles ? 2 * numTiles - 1 : e;
-            for (int sl = h; sl <= e; ++sl) {
-                const double* q = pieces.sums + (size_t)sl * kSumsPerTile;
+            const int first = t * kTile, last = (first + kTile < pieces.n ? first + kTile : pieces.n) - 1;
+            if (first < pieces.hi && last >= pieces.lo) {           // some of the tile was produced here
+                int h = pieces.headSlot[t], e = pieces.tailSlot[t];
+                h = h < 0 ? 0 : h;
+                e = e >= 2 * numTiles ? 2 * numTiles - 1 : e;
+                for (int sl = h; sl <= e; ++sl) {
+                    const double* q = pieces.sums + (size_t)sl * kSumsPerTile;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) v[k] += q[k];
+                }
+            }
+            if (first < pieces.lo || last >= pieces.hi) {           // some of it was received
+                const double* q = pieces.extra + (size_t)t * kSumsPerTile;
 #pragma unroll
                 for (int k = 0; k < 7; ++k) v[k] += q[k];
             }
@@ -388,9 +399,10 @@ __device__ __forceinline__ long long first_offspring_at(double b, double rStart,
 }
 
 // ------------------------------------------------------------------ resample
-// Staging arrays for offspring whose place is on another shard (sharded filters only; null otherwise):
-// x,y,z,theta of the offspring below this shard's own index range first, then those above it.
-struct StagePtrs { float* a[4]; long long cap; };
+// Staging area for offspring whose place is on another shard (sharded filters only; null otherwise): one
+// (x, y, z, theta) record per offspring, those below this shard's own index range first, then those above it --
+// one contiguous message per neighbour.
+struct StagePtrs { float4* rec; long long cap; };
 
 // Structure (measured, MI355X, N = 16 M): a version that gathered the ancestors from global memory with one dword
 // load per lane and stored one dword per lane and array ran at 0.14 ms whatever was left of its arithmetic; the
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, LocCtl*
                     } else {
                         const long long p = (k < kSelfB ? lo : hi) + k;
                         if (p >= stage.cap) continue;   // shard imbalance beyond the staging area: the host reports it
-                        stage.a[0][p] = ox[m]; stage.a[1][p] = oy[m]; stage.a[2][p] = oz[m]; stage.a[3][p] = ot[m];
+                        stage.rec[p] = make_float4(ox[m], oy[m], oz[m], ot[m]);
                     }
                 }
             }
@@ -581,22 +593,25 @@ struct ResampleDepositLds {
     float4 anc[kTile];
     double park[7 * 64];
     double red[4];
-    int span[2];
+    long long span[2];
 };
 
-template <bool MOTION>
+// SHARDED: the filter is one shard of a larger one (global indices selfBegin + local element).  Offspring whose index
+// falls outside the shard's own range are not deposited on here: they go to the staging area as they come out of the
+// resampling, and the shard that owns them deposits on them when they land (k_loc_land).
+template <bool MOTION, bool SHARDED>
 __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const LocCtl* __restrict__ ctl,
                                                       const double* __restrict__ chunkBase,
                                                       const double* __restrict__ tileIncl, int numTiles, int n,
                                                       const RngKey& keyRs, const RespawnShell& sh, const RngKey& key,
                                                       const Motion& mo, const Gate& ga, const PieceOut& out,
-                                                      ResampleDepositLds& L)
+                                                      const StagePtrs& stage, ResampleDepositLds& L)
 {
     double* const cdf = L.cdf;
     float4* const anc = L.anc;
     double* const park = L.park;
     double* const red = L.red;
-    int* const span = L.span;
+    long long* const span = L.span;
     double* __restrict__ pieceSums = out.sums;
     int* __restrict__ headSlot = out.headSlot;
     int* __restrict__ tailSlot = out.tailSlot;
@@ -612,14 +627,17 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
     const float4 t4 = *reinterpret_cast<const float4*>(bufs.a[src][4] + e0);
 
     const double rStart = ctl->rStart, rStep = ctl->rStep;
-    const double shardBase = ctl->shardBase, shardEnd = ctl->shardEnd;     // [0, S): the filter is not sharded
+    const double shardBase = ctl->shardBase, shardEnd = ctl->shardEnd;     // [0, S) unless the filter is sharded
     const double tileStart = tile_start_cdf(chunkBase, tileIncl, t, shardBase, shardEnd);
+    const long long gOff = SHARDED ? ctl->selfBegin : 0;                    // global index of local element 0
+    const long long nGlobal = SHARDED ? ctl->nGlobal : n;
+    const long long outBegin = SHARDED ? ctl->outBegin : 0, outEnd = SHARDED ? ctl->outEnd : n;
     if (tid == 0) {
-        span[0] = (t == 0) ? 0 : (int)first_offspring_at(tileStart, rStart, rStep, n);
+        span[0] = (t == 0) ? outBegin : first_offspring_at(tileStart, rStart, rStep, nGlobal);
     } else if (tid == 64) {
         span[1] = (t == numTiles - 1)
-                      ? n
-                      : (int)first_offspring_at(tile_start_cdf(chunkBase, tileIncl, t + 1, shardBase, shardEnd), rStart, rStep, n);
+                      ? outEnd
+                      : first_offspring_at(tile_start_cdf(chunkBase, tileIncl, t + 1, shardBase, shardEnd), rStart, rStep, nGlobal);
     }
 
     const double a0 = w4.x, a1 = a0 + w4.y, a2 = a1 + w4.z, a3 = a2 + w4.w;
@@ -638,15 +656,45 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
     anc[tid * 4 + 2] = make_float4(x4.z, y4.z, z4.z, t4.z);
     anc[tid * 4 + 3] = make_float4(x4.w, y4.w, z4.w, t4.w);
     __syncthreads();
-    const int i0 = span[0], i1 = span[1];
+    const long long s0 = span[0], s1 = span[1];         // global offspring span of this source tile
+    auto to_local = [&](long long g) -> int { g -= gOff; return g < 0 ? 0 : (g > n ? n : (int)g); };
+    const int i0 = to_local(s0), i1 = to_local(s1);     // the part of it that lands in this shard's own arrays
+    const int loL = to_local(outBegin), hiL = to_local(outEnd);     // local elements produced by this shard at all
+    const float hTheta = ctl->htheta;
+    const int numSpawn = ctl->numSpawn;
+    const double dOff = (double)gOff;
+
+    if (SHARDED) {
+        // foreign offspring: below the own range first, then above it, one record each
+        const long long selfEnd = gOff + n;
+        const long long below = gOff > outBegin ? (gOff < outEnd ? gOff : outEnd) - outBegin : 0;
+        const long long aboveStart = selfEnd > outBegin ? selfEnd : outBegin;
+#pragma unroll 1
+        for (int seg = 0; seg < 2; ++seg) {
+            const long long f0 = seg == 0 ? s0 : (s0 > selfEnd ? s0 : selfEnd);
+            const long long f1 = seg == 0 ? (s1 < gOff ? s1 : gOff) : s1;
+            for (long long i = f0 + tid; i < f1; i += kThreads) {
+                const double u = rStart + rStep * (double)i;
+                const int j = upper_bound_tile(cdf, nValid, u);
+                float x, y, z, th;
+                if (i < numSpawn) {
+                    spawn_from_range(keyRs, (uint64_t)i, sbx, sby, sbz, srange, sstd, x, y, z, th);
+                } else {
+                    const float4 a = anc[j];
+                    spawn_from_other(keyRs, (uint64_t)i, a.x, a.y, a.z, a.w, kHxyz, hTheta, x, y, z, th);
+                }
+                const long long p = seg == 0 ? i - outBegin : i - aboveStart + below;
+                if (p < stage.cap) stage.rec[p] = make_float4(x, y, z, th);     // beyond it: the host has reported the imbalance
+            }
+        }
+    }
+
     if (i0 >= i1) {
         // empty span at offspring position i0: a zero piece in the slot the walk would have used there
         if (tid < 7) pieceSums[(size_t)(t + i0 / kTile) * kSumsPerTile + tid] = 0.0;
         return;
     }
 
-    const float hTheta = ctl->htheta;
-    const int numSpawn = ctl->numSpawn;
     const bool smallTurn = mo.stdTheta <= 1e-4f;
     float* __restrict__ dw = bufs.a[dst][0];
     float* __restrict__ dx = bufs.a[dst][1];
@@ -660,10 +708,13 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
         const int slot = t + d;
         if (tid < 7) pieceSums[(size_t)slot * kSumsPerTile + tid] = v;
         if (tid == 0) {
-            const int first = d * kTile;
-            const int last = (first + kTile < n ? first + kTile : n) - 1;
-            if (i0 <= first) headSlot[d] = slot;            // first < i1 holds: the piece is not empty
-            if (last < i1) tailSlot[d] = slot;              // last >= i0 likewise
+            // first / last element of tile d that this shard produces itself ([loL, hiL) is all of it when unsharded)
+            int first = d * kTile;
+            int last = (first + kTile < n ? first + kTile : n) - 1;
+            first = first > loL ? first : loL;
+            last = last < hiL - 1 ? last : hiL - 1;
+            if (i0 <= first && first < i1) headSlot[d] = slot;
+            if (i0 <= last && last < i1) tailSlot[d] = slot;
         }
     };
 
@@ -680,7 +731,7 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
             int jj[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const double u = rStart + rStep * (double)(e + m);      // pfResample.c:71
+                const double u = rStart + rStep * (SHARDED ? dOff + (double)(e + m) : (double)(e + m));     // pfResample.c:71
                 jj[m] = upper_bound_tile(cdf, nValid, u);
             }
             float ow[4], ox[4], oy[4], oz[4], ot[4];
@@ -689,16 +740,17 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
                 const int i = e + m;
                 ow[m] = ox[m] = oy[m] = oz[m] = ot[m] = 0.0f;
                 if (i < i0 || i >= i1) continue;
-                if (i < numSpawn) {
-                    spawn_from_range(keyRs, (uint64_t)i, sbx, sby, sbz, srange, sstd, ox[m], oy[m], oz[m], ot[m]);
+                const uint64_t gi = (uint64_t)(gOff + i);   // global index: the Philox counter
+                if ((long long)gi < numSpawn) {
+                    spawn_from_range(keyRs, gi, sbx, sby, sbz, srange, sstd, ox[m], oy[m], oz[m], ot[m]);
                 } else {
                     const float4 a = anc[jj[m]];
-                    spawn_from_other(keyRs, (uint64_t)i, a.x, a.y, a.z, a.w, kHxyz, hTheta, ox[m], oy[m], oz[m], ot[m]);
+                    spawn_from_other(keyRs, gi, a.x, a.y, a.z, a.w, kHxyz, hTheta, ox[m], oy[m], oz[m], ot[m]);
                 }
                 // the new deposit on the fresh offspring (weight 1): the body of k_loc_stream
                 float wi = 1.0f, thi = ot[m], sn, cs;
                 if (MOTION) {
-                    motion_particle(key, (uint64_t)i, mo, smallTurn, ox[m], oy[m], oz[m], thi, sn, cs);
+                    motion_particle(key, gi, mo, smallTurn, ox[m], oy[m], oz[m], thi, sn, cs);
                 } else {
                     thi = wrap_two_pi(thi);
                     sincos_bounded(thi, sn, cs);
@@ -770,9 +822,78 @@ __global__ __launch_bounds__(kThreads) void k_loc_deposit(LocBufs bufs, const Lo
     static_assert(sizeof(ResampleDepositLds) >= 7 * kThreads * sizeof(double), "stream side needs 7 * kThreads doubles");
     __shared__ ResampleDepositLds L;
     if (ctl->branch == 1)
-        resample_deposit_tile<MOTION>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga, out, L);
+        resample_deposit_tile<MOTION, false>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga, out, StagePtrs{}, L);
     else
         stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, 0, key, mo, ga, reinterpret_cast<double*>(&L));
+}
+
+// The same for one shard of a sharded filter (global indices, foreign offspring staged).  The host launches it
+// before it has looked at the previous decision, so that waiting for that decision overlaps with this kernel.
+template <bool MOTION>
+__global__ __launch_bounds__(kThreads) void k_loc_deposit_sharded(LocBufs bufs, const LocCtl* __restrict__ ctl,
+                                                                 double* __restrict__ tileSums,
+                                                                 const double* __restrict__ chunkBase,
+                                                                 const double* __restrict__ tileIncl, int numTiles, int n,
+                                                                 long long idx0, RngKey keyRs, RespawnShell sh, RngKey key,
+                                                                 Motion mo, Gate ga, PieceOut out, StagePtrs stage)
+{
+    __shared__ ResampleDepositLds L;
+    if (ctl->branch == 1)
+        resample_deposit_tile<MOTION, true>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga, out, stage, L);
+    else
+        stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, idx0, key, mo, ga, reinterpret_cast<double*>(&L));
+}
+
+// Offspring received from the neighbouring shards: record k of `landing` belongs to local element k (k < lo: sent by
+// the shards below) or hi + (k - lo) (sent by the shards above); [lo, hi) is what this shard produced itself.  The
+// records are unpacked into the current SoA arrays with w = 1.  DEPOSIT: the pending deposit is applied on the way
+// (the body of k_loc_stream on a weight-1 particle, Philox counter = global index) and the seven sums of the
+// received elements of each tile go to `extra` (k_loc_chunks adds them to the tile's pieces).
+// Grid: the tiles that overlap [0, lo), then those that overlap [hi, n) (none of them twice).
+template <bool MOTION, bool DEPOSIT>
+__global__ __launch_bounds__(kThreads) void k_loc_land(LocBufs bufs, const LocCtl* __restrict__ ctl,
+                                                      const float4* __restrict__ landing, int lo, int hi, int n,
+                                                      int tilesBelow, int firstTileAbove, long long idx0, RngKey key,
+                                                      Motion mo, Gate ga, double* __restrict__ extra)
+{
+    __shared__ double red[DEPOSIT ? 7 * kThreads : 1];
+    const int tile = (int)blockIdx.x < tilesBelow ? (int)blockIdx.x : firstTileAbove + ((int)blockIdx.x - tilesBelow);
+    const int cur = ctl->cur;
+    float* __restrict__ pw = bufs.a[cur][0];
+    float* __restrict__ px = bufs.a[cur][1];
+    float* __restrict__ py = bufs.a[cur][2];
+    float* __restrict__ pz = bufs.a[cur][3];
+    float* __restrict__ pt = bufs.a[cur][4];
+    const bool smallTurn = mo.stdTheta <= 1e-4f;
+    double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        const int el = tile * kTile + (int)threadIdx.x * kPerThread + k;
+        if (el >= n || (el >= lo && el < hi)) continue;
+        const float4 r = landing[el < lo ? el : lo + (el - hi)];
+        float wi = 1.0f, x = r.x, y = r.y, z = r.z, th = r.w;
+        if (DEPOSIT) {
+            float sn, cs;
+            if (MOTION) {
+                motion_particle(key, (uint64_t)(idx0 + el), mo, smallTurn, x, y, z, th, sn, cs);
+            } else {
+                th = wrap_two_pi(th);
+                sincos_bounded(th, sn, cs);
+            }
+            const float gx = x - ga.bx, gy = y - ga.by, gz = z - ga.bz;
+            const float pRange = sqrtf(gx * gx + gy * gy + gz * gz);
+            if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
+            acc[0] += wi;
+            acc[1] += wi * wi;
+            acc[2] += wi * cs;
+            acc[3] += wi * sn;
+            acc[4] += wi * x;
+            acc[5] += wi * y;
+            acc[6] += wi * z;
+        }
+        pw[el] = wi; px[el] = x; py[el] = y; pz[el] = z; pt[el] = th;
+    }
+    if (DEPOSIT) block_sum_store<7>(acc, red, extra + (size_t)tile * kSumsPerTile);
 }
 
 // ------------------------------------------------------------------ pose sums after a resampling step

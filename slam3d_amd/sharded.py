@@ -10,9 +10,11 @@ Rank g holds the global particles [T_g, T_{g+1}), T_g = floor(g*N/G).  Per depos
   3. every rank takes the SAME decision from the gathered sums (same order of additions), and derives
      its span [base_g, base_{g+1}) of the global CDF and the global offspring range [F_g, F_{g+1}) its
      particles produce.  rStart comes from Philox(epoch), identical everywhere: no broadcast.
-  4. on a resampling step each rank resamples its own ancestors.  Offspring whose index falls in the
-     rank's own range are written in place; the others are staged and shipped point-to-point (xGMI) straight
-     into the owner's arrays, so every shard ends the step with exactly T_{g+1}-T_g particles again.
+  4. a "resample" decision stays pending until the next deposit (or the next read).  Then each rank resamples its
+     own ancestors and applies the new deposit to the offspring in the same pass.  Offspring whose index falls in
+     the rank's own range are written in place; the others are staged as (x, y, z, theta) records -- one
+     contiguous message per neighbour -- shipped point-to-point (xGMI) into the owner's landing area, unpacked
+     there and deposited on, so every shard ends the step with exactly T_{g+1}-T_g particles again.
      Particle noise is keyed by GLOBAL index, so the result does not depend on the number of shards.
 
 A non-resampling step moves no particle data at all.  The pose query all-reduces 6 doubles.
@@ -96,9 +98,10 @@ class GpuShard:
         dev = f"cuda:{self.device}"
         self._local = torch.as_tensor(_DevMem(self._L.pfx_loc_shard_local_ptr(self._h), 8, "<f8"), device=dev)
         self._all = torch.as_tensor(_DevMem(self._L.pfx_loc_shard_all_ptr(self._h), MAX_SHARDS * 8, "<f8"), device=dev)
-        st, b0, b1 = (C.c_void_p * 4)(), (C.c_void_p * 5)(), (C.c_void_p * 5)()
-        self._lib.check(self._L.pfx_loc_shard_ptrs_both(self._h, st, b0, b1), "pfx_loc_shard_ptrs_both")
-        self._stage = [torch.as_tensor(_DevMem(p, self.stage_capacity, "<f4"), device=dev) if p else None for p in st]
+        st, ld, b0, b1 = C.c_void_p(), C.c_void_p(), (C.c_void_p * 5)(), (C.c_void_p * 5)()
+        self._lib.check(self._L.pfx_loc_shard_ptrs_both(self._h, C.byref(st), C.byref(ld), b0, b1), "pfx_loc_shard_ptrs_both")
+        self._stage = torch.as_tensor(_DevMem(st.value, 4 * self.stage_capacity, "<f4"), device=dev)
+        self._landing = torch.as_tensor(_DevMem(ld.value, 4 * self.stage_capacity, "<f4"), device=dev)
         self._bufs = [[torch.as_tensor(_DevMem(p, self.n, "<f4"), device=dev) for p in b] for b in (b0, b1)]
 
     def close(self):
@@ -124,9 +127,13 @@ class GpuShard:
     def set_force_branch(self, force):
         self._L.pfx_loc_set_force_branch(self._h, int(force))
 
-    # -- the local halves of a deposit
-    def pass1(self, bx, by, bz, rng, std) -> int:
-        return self._lib.check(self._L.pfx_loc_shard_pass1(self._h, bx, by, bz, rng, std), "pfx_loc_shard_pass1")
+    # -- the local halves of a deposit (include/pfx.h, pfx_loc_shard_*)
+    def begin(self, bx, by, bz, rng, std) -> int:
+        return self._lib.check(self._L.pfx_loc_shard_begin(self._h, bx, by, bz, rng, std), "pfx_loc_shard_begin")
+
+    def deposit(self):
+        """the O(N) pass; acts on the previous decision on the device (resample-and-deposit, or stream)"""
+        self._lib.check(self._L.pfx_loc_shard_deposit(self._h), "pfx_loc_shard_deposit")
 
     def local_sums(self):
         return self._local
@@ -134,24 +141,32 @@ class GpuShard:
     def all_sums(self):
         return self._all[: self.world * 8]
 
-    def decide_resample(self, bx, by, bz, rng, std) -> Tuple[int, List[int]]:
-        """global decision + local resampling enqueued back to back; only the decision is waited for (the resample
-        kernel keeps running while the host plans the exchange)"""
-        self._lib.check(self._L.pfx_loc_shard_decide_resample(self._h, bx, by, bz, rng, std), "pfx_loc_shard_decide_resample")
+    def decide(self):
+        """the global decision, enqueued; nothing is waited for"""
+        self._lib.check(self._L.pfx_loc_shard_decide(self._h), "pfx_loc_shard_decide")
+
+    def plan(self) -> Tuple[int, List[int]]:
+        """waits for the last decision only (it lands in pinned host memory)"""
         br = C.c_int()
         F = (C.c_int64 * (MAX_SHARDS + 1))()
         self._lib.check(self._L.pfx_loc_shard_plan(self._h, C.byref(br), F), "pfx_loc_shard_plan")
         return br.value, [int(F[k]) for k in range(self.world + 1)]
 
-    def stage_views(self, off, count):
-        return [s[off: off + count] for s in self._stage]
+    def produce(self):
+        self._lib.check(self._L.pfx_loc_shard_produce(self._h), "pfx_loc_shard_produce")
 
-    def current_views(self, off, count):
-        """x, y, z, theta slices of the current arrays"""
-        return [a[off: off + count] for a in self._curr[1:]]
+    def land(self, deposit: bool, lo: int, hi: int):
+        self._lib.check(self._L.pfx_loc_shard_land(self._h, int(deposit), lo, hi), "pfx_loc_shard_land")
 
-    def fill_w(self, off, count):
-        self._curr[0][off: off + count].fill_(1.0)
+    def finish(self, pieces: bool, lo: int = 0, hi: int = 0):
+        self._lib.check(self._L.pfx_loc_shard_finish(self._h, int(pieces), lo, hi), "pfx_loc_shard_finish")
+
+    def stage_view(self, off, count):
+        """records off .. off+count of the send half of the staging area, as one flat float32 tensor"""
+        return self._stage[4 * off: 4 * (off + count)]
+
+    def landing_view(self, off, count):
+        return self._landing[4 * off: 4 * (off + count)]
 
     def pose_sums(self):
         out = (C.c_double * 6)()
@@ -217,8 +232,9 @@ class ShardedLocFilter:
         self.stage_capacity = cap
         self._pg_is_nccl = dist.get_backend(group) == "nccl"
         self.initialized = False
-        self.last_branch = None
-        self.last_F = None
+        self._outstanding = False               # a decision has been launched and not acted on yet
+        self._decided = False                   # ... at least one has been launched
+        self._plan_cache = None
         self.exchanged_particles = 0
 
     # -- collectives (device tensors go straight to RCCL; under gloo they are staged through the host)
@@ -233,27 +249,63 @@ class ShardedLocFilter:
             out_t.copy_(h_out)
 
     def _p2p(self, sends, recvs):
-        """sends/recvs: lists of (peer, [tensors])"""
+        """sends/recvs: lists of (peer, tensor)"""
         dist, torch = self._dist, self._torch
         if not sends and not recvs:
             return
-        staged = not self._pg_is_nccl and any(t.is_cuda for _, ts in sends + recvs for t in ts)
+        staged = not self._pg_is_nccl and any(t.is_cuda for _, t in sends + recvs)
         ops, back = [], []
-        for peer, ts in recvs:
-            for t in ts:
-                if staged:
-                    h = torch.empty(t.shape, dtype=t.dtype)
-                    back.append((t, h))
-                    ops.append(dist.P2POp(dist.irecv, h, peer, group=self.group))
-                else:
-                    ops.append(dist.P2POp(dist.irecv, t, peer, group=self.group))
-        for peer, ts in sends:
-            for t in ts:
-                ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer, group=self.group))
+        for peer, t in recvs:
+            if staged:
+                h = torch.empty(t.shape, dtype=t.dtype)
+                back.append((t, h))
+                ops.append(dist.P2POp(dist.irecv, h, peer, group=self.group))
+            else:
+                ops.append(dist.P2POp(dist.irecv, t, peer, group=self.group))
+        for peer, t in sends:
+            ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer, group=self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         for t, h in back:
             t.copy_(h)
+
+    def _plan(self):
+        """(branch, F) of the outstanding decision; read once, when first needed"""
+        if self._plan_cache is None:
+            self._plan_cache = self.shard.plan()
+        return self._plan_cache
+
+    @property
+    def last_branch(self):
+        return self._plan()[0] if self._decided else None
+
+    @property
+    def last_F(self):
+        return self._plan()[1] if self._decided else None
+
+    def _ship_and_land(self, F, deposit: bool):
+        """after the offspring of a "resample" decision have been produced: the foreign ones go to their owners, what
+        arrives is unpacked (deposit: and deposited on)"""
+        sh, T, r = self.shard, self.T, self.rank
+        sends, recvs, _below = exchange_plan(F, T, r)
+        lo = min(max(F[r], T[r]), T[r + 1]) - T[r]              # the local elements [lo, hi) were produced here
+        hi = max(max(min(F[r + 1], T[r + 1]), T[r]) - T[r], lo)
+        # record k of the landing area: local element k (k < lo) or hi + (k - lo)
+        self._p2p([(p, sh.stage_view(off, cnt)) for p, off, cnt in sends],
+                  [(p, sh.landing_view(off if off < lo else lo + (off - hi), cnt)) for p, off, cnt in recvs])
+        sh.land(deposit, lo, hi)
+        self.exchanged_particles += sum(c for _, _, c in sends)
+        return lo, hi
+
+    def _settle(self):
+        """before anything reads the particles: produce a resampling that is still outstanding, without a deposit"""
+        if not self._outstanding:
+            return
+        self._outstanding = False
+        branch, F = self._plan()
+        if branch:
+            self.shard.produce()
+            self._ship_and_land(F, False)
 
     # -- the wrapper interface
     def depositVio(self, t, x, y, z, dist_):
@@ -261,21 +313,25 @@ class ShardedLocFilter:
 
     def depositRange(self, bx, by, bz, range, stdRange):        # noqa: A002
         sh = self.shard
-        if sh.pass1(bx, by, bz, range, stdRange) == 1:
+        if sh.begin(bx, by, bz, range, stdRange) == 1:
             self.initialized = True             # first range: every shard spawned its own particles
+            self._outstanding = self._decided = False
             return
+        # The pass over the particles goes first: the kernel itself acts on the previous decision (resampling fused
+        # with this deposit, or plain streaming).  Only then does the host look at that decision -- by now it has
+        # long landed -- to find out whether offspring have to be shipped.
+        sh.deposit()
+        branch, F = self._plan() if self._outstanding else (0, None)
+        self._outstanding = False
+        if branch:
+            lo, hi = self._ship_and_land(F, True)
+            sh.finish(True, lo, hi)
+        else:
+            sh.finish(False)
         self._all_gather(sh.all_sums(), sh.local_sums())
-        branch, F = sh.decide_resample(bx, by, bz, range, stdRange)
-        self.last_branch, self.last_F = branch, F
-        if not branch:
-            return
-        sends, recvs, _below = exchange_plan(F, self.T, self.rank)
-        staged = sum(c for _, _, c in sends)
-        self._p2p([(p, sh.stage_views(off, cnt)) for p, off, cnt in sends],
-                  [(p, sh.current_views(off, cnt)) for p, off, cnt in recvs])
-        for _p, off, cnt in recvs:
-            sh.fill_w(off, cnt)
-        self.exchanged_particles += staged
+        sh.decide()
+        self._outstanding = self._decided = True
+        self._plan_cache = None
 
     def depositRssi(self, bx, by, bz, rssi):
         self.depositRange(bx, by, bz, 1.5, 0.5)        # particleFilter.c:213-226
@@ -284,6 +340,7 @@ class ShardedLocFilter:
         torch, dist = self._torch, self._dist
         if not self.initialized:
             return (0, 0.0, np.float32(0), np.float32(0), np.float32(0), np.float32(0))
+        self._settle()
         sums = torch.from_numpy(self.shard.pose_sums())
         if self._pg_is_nccl:
             d = sums.cuda()
@@ -307,4 +364,5 @@ class ShardedLocFilter:
         return self.shard.branch_log()
 
     def download_local(self):
+        self._settle()
         return self.shard.download()

@@ -46,7 +46,8 @@ class OracleShard:
         self.stage_capacity = stage_capacity
         self._local = torch.zeros(8, dtype=torch.float64)
         self._all = torch.zeros(world * 8, dtype=torch.float64)
-        self._stage = [torch.zeros(stage_capacity, dtype=torch.float32) for _ in range(4)]
+        self._stage = torch.zeros(4 * stage_capacity, dtype=torch.float32)      # (x, y, z, theta) records to send
+        self._landing = torch.zeros(4 * stage_capacity, dtype=torch.float32)    # records received
         self.pose_local = None
         self.wscale = f32(1.0)
         self.force = -1
@@ -73,20 +74,38 @@ class OracleShard:
         L.ora_loc_commit_vio(self.pf.h, d)
         return [f32(v) for v in d]
 
-    def pass1(self, bx, by, bz, rng, std):
+    def begin(self, bx, by, bz, rng, std):
         self.epoch += 1
         self.pf.epoch = self.epoch
-        d = self._commit()
+        self._vio = self._commit()
+        self._args = (bx, by, bz, rng, std)
         if not self.pf.initialized:
             self.pf.spawn_all(bx, by, bz, rng, std)
             self.pf.set_initialized(1)
             self.branch = 1
             self.pose_local = None
+            self._outstanding = False
             return 1
+        return 0
+
+    def deposit(self):
+        """acts on the outstanding decision as the device kernel does: after "resample" the offspring are produced
+        (the deposit on them follows in land(), for the whole shard at once: same per-particle arithmetic), after
+        "normalise" -- or with nothing outstanding -- the streaming pass"""
+        if getattr(self, "_outstanding", False) and self.branch:
+            self._outstanding = False
+            self._resample()
+        else:
+            self._outstanding = False
+            self.stream()
+
+    def stream(self):
+        """VIO motion + gate over all local particles and the 8 local sums"""
+        bx, by, bz, rng, std = self._args
         w, x, y, z, th = self.pf.arrays()
         w *= self.wscale                                  # pending normalisation (pfResample.c:80-82)
         self.wscale = f32(1.0)
-        self.pf.apply_vio(*d)
+        self.pf.apply_vio(*self._vio)
         self.pf.apply_range(bx, by, bz, rng, std)
         w64 = w.astype(np.float64)
         c, s = np.cos(th).astype(np.float32), np.sin(th).astype(np.float32)
@@ -94,7 +113,6 @@ class OracleShard:
                 (w * s).astype(np.float64).sum(), (w * x).astype(np.float64).sum(), (w * y).astype(np.float64).sum(),
                 (w * z).astype(np.float64).sum(), 0.0]
         self._local[:] = torch.tensor(sums, dtype=torch.float64)
-        return 0
 
     def local_sums(self):
         return self._local
@@ -102,7 +120,8 @@ class OracleShard:
     def all_sums(self):
         return self._all
 
-    def decide(self, rng):
+    def decide(self):
+        rng = self._args[3]
         a = self._all.numpy().reshape(self.world, 8)
         tot = np.zeros(7)
         base = [0.0]
@@ -123,16 +142,20 @@ class OracleShard:
             self.pose_local = np.array([l[0], l[4], l[5], l[6], l[2], l[3]])
             F = [0] * (self.world + 1)
         self.F = F
-        return self.branch, F
+        self._outstanding = True
+        if self.branch:
+            self._rs = (self.epoch, self._args)           # what the resampling will need
 
-    def decide_resample(self, bx, by, bz, rng, std):
-        """the GpuShard interface: decision and (if it says so) the local resampling in one call"""
-        branch, F = self.decide(rng)
-        if branch:
-            self.resample(bx, by, bz, rng, std)
-        return branch, F
+    def plan(self):
+        return self.branch, self.F
 
-    def resample(self, bx, by, bz, rng, std):
+    def produce(self):
+        self._outstanding = False
+        self._resample()
+
+    def _resample(self):
+        """own-range offspring into the arrays (weight 1), foreign ones staged as records"""
+        epoch, (bx, by, bz, rng, std) = self._rs
         w, x, y, z, th = self.pf.arrays()
         cdf = self.base[self.rank] + np.cumsum(w.astype(np.float64))
         ob, oe = self.F[self.rank], self.F[self.rank + 1]
@@ -141,7 +164,7 @@ class OracleShard:
         u = self.r_start + self.r_step * i
         anc = np.minimum(np.searchsorted(cdf, u, side="right"), self.n - 1).astype(np.int32)
         ox, oy, oz, ot = (np.empty(cnt, dtype=np.float32) for _ in range(4))
-        ora.lib().ora_offspring_block(self.rng.h, 0, self.epoch, ob, cnt, _p(anc, C.c_int), _p(x), _p(y), _p(z), _p(th),
+        ora.lib().ora_offspring_block(self.rng.h, 0, epoch, ob, cnt, _p(anc, C.c_int), _p(x), _p(y), _p(z), _p(th),
                                       self.htheta, self.num_spawn, bx, by, bz, rng, std, _p(ox), _p(oy), _p(oz), _p(ot))
         # producer-side pose partials (w = 1)
         self.pose_local = np.array([cnt, ox.astype(np.float64).sum(), oy.astype(np.float64).sum(), oz.astype(np.float64).sum(),
@@ -153,26 +176,44 @@ class OracleShard:
         nb = int(below.sum())
         new = [np.zeros(self.n, dtype=np.float32) for _ in range(5)]
         new[0][gi[own] - sb] = 1.0
+        st = self._stage.numpy().reshape(-1, 4)
+        na = int((gi >= se).sum())
         for k, o in enumerate((ox, oy, oz, ot)):
             new[k + 1][gi[own] - sb] = o[own]
-            st = self._stage[k].numpy()
-            st[:nb] = o[below]
-            na = int((gi >= se).sum())
-            st[nb:nb + na] = o[gi >= se]
+            st[:nb, k] = o[below]
+            st[nb:nb + na, k] = o[gi >= se]
         self._new = new
         # install as the current arrays
         for dst, src in zip(self.pf.arrays(), new):
             dst[:] = src
 
-    def stage_views(self, off, count):
-        return [s[off: off + count] for s in self._stage]
+    def stage_view(self, off, count):
+        return self._stage[4 * off: 4 * (off + count)]
 
-    def current_views(self, off, count):
+    def landing_view(self, off, count):
+        return self._landing[4 * off: 4 * (off + count)]
+
+    def land(self, deposit, lo, hi):
+        """records of the landing area -> local elements [0, lo) and [hi, n), weight 1; deposit: then the deposit just
+        begun on every local particle (the produced ones were left undeposited by produce())"""
         arrs = self.pf.arrays()
-        return [torch.from_numpy(a)[off: off + count] for a in arrs[1:]]
+        rec = self._landing.numpy().reshape(-1, 4)
+        na = self.n - hi
+        arrs[0][:lo] = 1.0
+        arrs[0][hi:] = 1.0
+        for k in range(4):
+            arrs[k + 1][:lo] = rec[:lo, k]
+            arrs[k + 1][hi:] = rec[lo:lo + na, k]
+        if deposit:
+            self.stream()
+        else:
+            w, x, y, z, th = arrs
+            self.pose_local = np.array([w.astype(np.float64).sum(), x.astype(np.float64).sum(), y.astype(np.float64).sum(),
+                                        z.astype(np.float64).sum(), np.cos(th).astype(np.float64).sum(),
+                                        np.sin(th).astype(np.float64).sum()])
 
-    def fill_w(self, off, count):
-        self.pf.arrays()[0][off: off + count] = 1.0
+    def finish(self, pieces, lo=0, hi=0):
+        pass                                              # land(deposit=True) has left the local sums
 
     def pose_sums(self):
         if self.pose_local is None:

@@ -32,11 +32,11 @@ def _free_port():
     return p
 
 
-def _run(world, backend, n, steps, force=-1, timeout=300):
+def _run(world, backend, n, steps, force=-1, timeout=300, pose_every=1):
     out = tempfile.mkdtemp(prefix="shard_")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), WORKER,
-           "--backend", backend, "--pg", "gloo", "--particles", str(n), "--steps", str(steps), "--force", str(force), "--out", out]
+           "--backend", backend, "--pg", "gloo", "--particles", str(n), "--steps", str(steps), "--force", str(force), "--pose-every", str(pose_every), "--out", out]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -90,30 +90,34 @@ def test_exchange_plan_is_a_partition():
             assert kept[g] + recv_total[g] == T[g + 1] - T[g]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_oracle_matches_unsharded(ora, world):
+@pytest.mark.parametrize("world,pose_every", [(2, 1), (3, 1), (2, 4), (3, 5)])
+def test_sharded_oracle_matches_unsharded(ora, world, pose_every):
+    """pose_every > 1: most resampling decisions stay pending until the next deposit (produce / ship / land with the
+    deposit applied); pose_every = 1: every one is materialised by the pose query right after it."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import sharded_worker as W
     n, steps = 6001, 14
     o = ora.OracleLoc(n, rng_mode=ora.RNG_PHILOX, seed=123456789, acc=ora.ACC_F64)
     branches = []
-    poses = W.drive(o, W.events(steps), lambda f: branches.append(int(f.last_stats()["branch"])))
-    shards = _run(world, "oracle", n, steps)
+    poses = W.drive(o, W.events(steps), lambda f: branches.append(int(f.last_stats()["branch"])), pose_every)
+    shards = _run(world, "oracle", n, steps, pose_every=pose_every)
     _compare(shards, [a.copy() for a in o.arrays()], poses, np.array(branches), n, tol=1e-6)
     assert shards[0]["branches"][1:].max() == 1, "the scene must exercise the resampling exchange"
     assert max(int(s["moved"][-1]) for s in shards) > 0, "no particle ever crossed a shard boundary"
 
 
 @pytest.mark.gpu
-def test_sharded_gpu_two_ranks_match_single_gpu():
+@pytest.mark.parametrize("world,pose_every", [(2, 1), (2, 4), (3, 3)])
+def test_sharded_gpu_ranks_match_single_gpu(world, pose_every):
+    """the real kernels: eager resampling + landing (pose_every = 1) and the fused produce / land / finish path"""
     from slam3d_amd import particlefilter as pfm
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import sharded_worker as W
     n, steps = 300007, 14
     g = pfm.DeviceParticleFilterLoc(n, seed=123456789)
     branches = []
-    poses = W.drive(g, W.events(steps), lambda f: branches.append(int(f.last_stats()["branch"])))
+    poses = W.drive(g, W.events(steps), lambda f: branches.append(int(f.last_stats()["branch"])), pose_every)
     ref = g.download()
-    shards = _run(2, "gpu", n, steps)
+    shards = _run(world, "gpu", n, steps, pose_every=pose_every)
     _compare(shards, ref, poses, np.array(branches), n, tol=1e-6)
     assert max(int(s["moved"][-1]) for s in shards) > 0

@@ -31,8 +31,11 @@ def events(n_steps):
     return ev
 
 
-def drive(pf, evs, on_deposit=None):
+def drive(pf, evs, on_deposit=None, pose_every=1):
+    """pose_every = K: the pose is read after every K-th deposit only, so that the deposits in between run with
+    their resampling deferred (fused with the next deposit)"""
     poses = []
+    k = 0
     for e in evs:
         if e[0] == "vio":
             pf.depositVio(*e[1:])
@@ -41,7 +44,9 @@ def drive(pf, evs, on_deposit=None):
             pf.depositRange(*e[1:])
         else:
             pf.depositRssi(*e[1:])
-        poses.append([float(v) for v in pf.getTagLoc()])
+        k += 1
+        if k % pose_every == 0:
+            poses.append([float(v) for v in pf.getTagLoc()])
         if on_deposit:
             on_deposit(pf)
     return np.array(poses)
@@ -55,6 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--seed", type=int, default=123456789)
     ap.add_argument("--force", type=int, default=-1)
+    ap.add_argument("--pose-every", type=int, default=1)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
@@ -77,7 +83,7 @@ def main():
     def tap(f):
         branches.append(-1 if f.last_branch is None else int(f.last_branch))
         moved.append(f.exchanged_particles)
-    poses = drive(pf, events(a.steps), tap)
+    poses = drive(pf, events(a.steps), tap, a.pose_every)
     w, x, y, z, th = pf.download_local()
     np.savez(os.path.join(a.out, f"rank{rank}.npz"), w=w, x=x, y=y, z=z, th=th, poses=poses,
              branches=np.array(branches), moved=np.array(moved), T=np.array(pf.T))
