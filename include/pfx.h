@@ -59,7 +59,7 @@ int      pfx_loc_set_force_branch(pfx_loc* pf, int force);
 /* 1 (default): the resample kernel a deposit calls for (pfResample.c:70-76) is deferred until the next deposit and
  * then runs fused with that deposit's motion + gate + sums (one pass over the offspring instead of two), or until
  * something else reads the particles; 0: every deposit launches its own resample kernel.  Same particles either
- * way.  Sharded filters and ancestor recording always run undeferred. */
+ * way.  Ancestor recording always runs undeferred; sharded filters follow the pfx_loc_shard_* protocol below. */
 int      pfx_loc_set_deferred(pfx_loc* pf, int enable);
 
 /* the reference's four operations (particleFilter.c:70-104, 178-191, 213-226, 248-291) */
