@@ -362,12 +362,6 @@ __global__ void k_loc_shard_decide(LocCtl* __restrict__ ctl, const double* __res
     __hip_atomic_store(&plan->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ void k_fill(float* __restrict__ p, float v, long long count)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) p[i] = v;
-}
-
 // CDF value at the START of tile t (t in [0, numTiles]).  The same expression is evaluated by the
 // workgroups on both sides of a boundary, and it is non-decreasing in t: inside a chunk tileIncl is
 // non-decreasing and the sum is capped by the next chunk's base.
