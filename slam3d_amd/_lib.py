@@ -26,6 +26,14 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C slam3d_amd/csrc` "
                           "(there is no fallback implementation)")
+    # PyTorch's ROCm wheel ships its own copies of the HIP / HSA runtime libraries.  A process can hold only one of
+    # them: if this library (linked against /opt/rocm) initialises the GPU first, torch.cuda later finds "no HIP GPUs".
+    # Loading torch first makes both share torch's copies (same SONAMEs), which is the order bench.py and the sharded
+    # filter have always used.  Set PFX_PRELOAD_TORCH=0 in processes that will never touch torch.cuda.
+    if os.environ.get("PFX_PRELOAD_TORCH", "1") != "0":
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, f, d, i, i64, u32 = C.c_void_p, C.c_float, C.c_double, C.c_int, C.c_int64, C.c_uint32
     pf_, pd_ = C.POINTER(C.c_float), C.POINTER(C.c_double)
