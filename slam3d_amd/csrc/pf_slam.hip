@@ -257,8 +257,12 @@ int slam_step(pfx_slam* pf, const StepReq* req, int nReq)
         pf->ringUsed[slot] = true;
     }
     if (anyUpdate) {
-        hipLaunchKernelGGL(k_slam_gate_rows, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo, pf->rowSum,
-                           pf->rowScale, pf->rowFlag, pf->forcedList + F);
+        if (anyMoving)
+            hipLaunchKernelGGL(k_slam_gate_rows<true>, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo,
+                               pf->rowSum, pf->rowScale, pf->rowFlag, pf->forcedList + F);
+        else
+            hipLaunchKernelGGL(k_slam_gate_rows<false>, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo,
+                               pf->rowSum, pf->rowScale, pf->rowFlag, pf->forcedList + F);
         if (check_launch("k_slam_gate_rows")) return -1;
     }
     hipLaunchKernelGGL(k_slam_tag, dim3(F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->rowSum, pf->tagBranch, pf->forcedList,

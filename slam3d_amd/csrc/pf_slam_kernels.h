@@ -75,30 +75,43 @@ __device__ __forceinline__ void row_store1(float* a, size_t base, int j0, int n,
 // particles, :165-184 for a beacon row) on the totals S = sum w (f64), SS, C, SN.
 struct SmallDecision { int resample, numSpawn; float htheta, m; double rStart, rStep; };
 
-__device__ __forceinline__ SmallDecision small_decide(double S, double SS, double C, double SN, int n, float range,
-                                                      bool allowSpawn, bool force, const RngKey& key, uint64_t rsIndex)
+// Part 1: the ESS / respawn test (needs only S and SS).  Part 2, for a filter that resamples: heading bandwidth from
+// the circular sums, rStep, rStart.  small_decide is the two in a row.
+__device__ __forceinline__ SmallDecision small_decide_test(double S, double SS, int n, float range, bool allowSpawn, bool force)
 {
     SmallDecision d;
     const float s = (float)S, ss = (float)SS;
-    float csum = (float)C, ssum = (float)SN;
     const float ess = s * s / ss;
     const float invN = 1.0f / (float)n;
     d.numSpawn = 0;
     if (allowSpawn && s * invN < kWeightSpawnThresh && range < kRadiusSpawnThresh) d.numSpawn = (int)lroundf((float)n * kPctSpawn);
     d.resample = ((ess * invN < kResampleThresh) || d.numSpawn > 0 || force) ? 1 : 0;
     d.htheta = 0.0f; d.m = 0.0f; d.rStart = 0.0; d.rStep = 0.0;
-    if (d.resample) {
-        csum /= s;
-        ssum /= s;
-        float h = csum * csum + ssum * ssum;
-        h = h > 1e-10f ? h : 1e-10f;
-        h = h < 1.0f - 1e-10f ? h : 1.0f - 1e-10f;
-        d.htheta = sqrtf(-logf(h) / ess);
-        d.rStep = S / (double)n;
-        d.rStart = (double)uniform01(rng_block(key, P_RSTART, rsIndex, 0).a) * d.rStep;
-    } else {
-        d.m = (float)n / s;
-    }
+    if (!d.resample) d.m = (float)n / s;
+    return d;
+}
+
+__device__ __forceinline__ void small_decide_spread(SmallDecision& d, double S, double SS, double C, double SN, int n,
+                                                    const RngKey& key, uint64_t rsIndex)
+{
+    const float s = (float)S, ss = (float)SS;
+    const float ess = s * s / ss;
+    float csum = (float)C, ssum = (float)SN;
+    csum /= s;
+    ssum /= s;
+    float h = csum * csum + ssum * ssum;
+    h = h > 1e-10f ? h : 1e-10f;
+    h = h < 1.0f - 1e-10f ? h : 1.0f - 1e-10f;
+    d.htheta = sqrtf(-logf(h) / ess);
+    d.rStep = S / (double)n;
+    d.rStart = (double)uniform01(rng_block(key, P_RSTART, rsIndex, 0).a) * d.rStep;
+}
+
+__device__ __forceinline__ SmallDecision small_decide(double S, double SS, double C, double SN, int n, float range,
+                                                      bool allowSpawn, bool force, const RngKey& key, uint64_t rsIndex)
+{
+    SmallDecision d = small_decide_test(S, SS, n, range, allowSpawn, force);
+    if (d.resample) small_decide_spread(d, S, SS, C, SN, n, key, rsIndex);
     return d;
 }
 
@@ -200,9 +213,119 @@ __device__ __forceinline__ SmallDecision small_filter_update(Row4& r, const floa
     return d;
 }
 
+// The same for a row whose headings have not been read: a row that only normalises never needs them (the circular sums
+// feed the heading bandwidth of a resampling, pfResample.c:171-176, nothing else), which saves it a fifth of its reads
+// and a sincos per particle.  Phase 1 reduces sum w and sum w^2 and tests; a resampling row then loads its headings
+// (thSrc + j0, one float4 per thread), reduces the circular sums, and goes on as small_filter_update does.
+// The headings are left unwrapped (pfMeasurement.c:104 with zero motion is theta = fmodf(theta, 2 pi): a no-op for every
+// stored heading except an initial one of exactly 2 pi_f, probability 2^-31 per spawned particle, which then keeps that
+// value -- equal modulo 2 pi -- until the row next resamples).
+__device__ __forceinline__ SmallDecision small_filter_update_lazy_theta(Row4& r, const float* __restrict__ thSrc, int j0, int n,
+                                                                        SmallLds& L, const RngKey& key, uint64_t index0,
+                                                                        uint64_t rsIndex, float range, float stdRange,
+                                                                        float cx, float cy, float cz,
+                                                                        float* __restrict__ rowSumOut)
+{
+    const int tid = threadIdx.x;
+    double acc[2] = { 0, 0 };           // s, ss
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float wi = (j0 + k < n) ? r.w[k] : 0.0f;
+        acc[0] += wi;
+        acc[1] += wi * wi;
+    }
+    double* const park = L.cdf;         // 2 * kThreads doubles here
+    auto reduce2 = [&](const double (&v)[2]) {      // totals in L.red[0], L.red[1]
+        park[tid] = v[0];
+        park[kThreads + tid] = v[1];
+        __syncthreads();
+        if (tid < 2 * 32) {
+            const int k = tid >> 5, j = tid & 31;
+            const double* p = park + k * kThreads + j;
+            double t = p[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) t += p[32 * i];
+            park[k * kThreads + j] = t;
+        }
+        __syncthreads();
+        if (tid < 2) {
+            const double* p = park + tid * kThreads;
+            double t = p[0];
+#pragma unroll
+            for (int j = 1; j < 32; ++j) t += p[j];
+            L.red[tid] = t;
+        }
+        __syncthreads();
+    };
+    reduce2(acc);
+    if (tid == 0) {
+        *rowSumOut = (float)L.red[0];
+        L.red[2] = L.red[0];            // S and SS survive the second reduction
+        L.red[3] = L.red[1];
+        L.dec = small_decide_test(L.red[0], L.red[1], n, range, true, false);
+    }
+    __syncthreads();
+    SmallDecision d = L.dec;
+    if (!d.resample) return d;          // uniform over the workgroup
+
+    const float4 t4 = (j0 < n) ? *reinterpret_cast<const float4*>(thSrc + j0) : make_float4(0, 0, 0, 0);
+    r.th[0] = t4.x; r.th[1] = t4.y; r.th[2] = t4.z; r.th[3] = t4.w;
+    double cs2[2] = { 0, 0 };           // c, sn
+    double a[4];
+    double run = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float wi = (j0 + k < n) ? r.w[k] : 0.0f;
+        run += wi;
+        a[k] = run;
+        r.th[k] = wrap_two_pi(r.th[k]);
+        float sn, cs;
+        sincos_bounded(r.th[k], sn, cs);
+        cs2[0] += wi * cs;
+        cs2[1] += wi * sn;
+    }
+    reduce2(cs2);
+    if (tid == 0) {
+        SmallDecision dd = L.dec;
+        small_decide_spread(dd, L.red[2], L.red[3], L.red[0], L.red[1], n, key, rsIndex);
+        L.dec = dd;
+    }
+    __syncthreads();
+    d = L.dec;
+    double total;
+    const double incl = block_inclusive_scan(run, L.scan, total);
+    const double off = incl - run;
+    const double inf = __builtin_huge_val();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = j0 + k;
+        L.cdf[j] = (j < n) ? off + a[k] : inf;
+        L.x[j] = r.x[k]; L.y[j] = r.y[k]; L.z[j] = r.z[k]; L.th[j] = r.th[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = j0 + k;
+        if (i >= n) continue;
+        if (i < d.numSpawn) {
+            spawn_from_range(key, index0 + (uint64_t)i, cx, cy, cz, range, stdRange, r.x[k], r.y[k], r.z[k], r.th[k]);
+        } else {
+            const double u = d.rStart + d.rStep * (double)i;        // pfResample.c:180
+            const int j = upper_bound_tile(L.cdf, n, u);
+            spawn_from_other(key, index0 + (uint64_t)i, L.x[j], L.y[j], L.z[j], L.th[j], kHxyz, d.htheta,
+                             r.x[k], r.y[k], r.z[k], r.th[k]);
+        }
+        r.w[k] = 1.0f;
+    }
+    return d;
+}
+
 // ------------------------------------------------------------------ the measured beacon: gate + row step, one pass
 // rowScale[slot row]: pending factor on the stored weights of that row (1 after a resample / spawn).
 // rowFlag[f * nTag + i]: 0 = row i was normalised (lazily), 1 + numSpawn = it was resampled here.
+// ANY_MOVING = false (the host knows that no beacon of the batch moved since its last deposit -- beacons are anchors,
+// csvslam.c never deposits beacon VIO): the headings are not read unless the row resamples (small_filter_update_lazy_theta).
+template <bool ANY_MOVING>
 __global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
                                                             const Motion* __restrict__ bcnMo, float* __restrict__ rowSum,
                                                             float* __restrict__ rowScale, int* __restrict__ rowFlag,
@@ -219,9 +342,19 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDim
     const size_t base = slam_row_base(D, f, c, i);
     const size_t srow = ((size_t)f * D.maxBcns + c) * D.nTag + i;
     const float scale = rowScale[srow];
-    const float* const src[5] = { P.bcn[0], P.bcn[1], P.bcn[2], P.bcn[3], P.bcn[4] };
+    const bool moving = ANY_MOVING && ((st.movingMask >> c) & 1u);
     Row4 r;
-    row_load(src, base, j0, n, r);
+    {
+        float4 v[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            v[q] = (j0 < n && (q < 4 || moving)) ? *reinterpret_cast<const float4*>(P.bcn[q] + base + j0) : make_float4(0, 0, 0, 0);
+        r.w[0] = v[0].x; r.w[1] = v[0].y; r.w[2] = v[0].z; r.w[3] = v[0].w;
+        r.x[0] = v[1].x; r.x[1] = v[1].y; r.x[2] = v[1].z; r.x[3] = v[1].w;
+        r.y[0] = v[2].x; r.y[1] = v[2].y; r.y[2] = v[2].z; r.y[3] = v[2].w;
+        r.z[0] = v[3].x; r.z[1] = v[3].y; r.z[2] = v[3].z; r.z[3] = v[3].w;
+        r.th[0] = v[4].x; r.th[1] = v[4].y; r.th[2] = v[4].z; r.th[3] = v[4].w;
+    }
 
     // tag particle i after its VIO motion (stored by k_slam_tag, which runs after every row has read the old one):
     // one lane computes it while the row loads are in flight, the others pick it up from LDS
@@ -237,26 +370,17 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDim
     __syncthreads();
     const float tx = tagp[0], ty = tagp[1], tz = tagp[2];
 
-    const bool moving = (st.movingMask >> c) & 1u;
+    const RngKey key{ st.seed, (uint32_t)(c + 1), st.epoch };
     Motion mo{};
     if (moving) mo = bcnMo[(size_t)f * D.maxBcns + c];
     const bool smallTurn = mo.stdTheta <= 1e-4f;
-    const RngKey key{ st.seed, (uint32_t)(c + 1), st.epoch };
-    bool thetaChanged = false;
     float sn[4] = { 0, 0, 0, 0 }, cs[4] = { 1, 1, 1, 1 };
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int j = j0 + k;
         if (j >= n) continue;
         r.w[k] *= scale;                    // pending normalisation of an earlier deposit (pfResample.c:195-199)
-        if (moving) {
-            motion_particle(key, (uint64_t)i * n + j, mo, smallTurn, r.x[k], r.y[k], r.z[k], r.th[k], sn[k], cs[k]);
-        } else {
-            const float t2 = wrap_two_pi(r.th[k]);
-            thetaChanged |= (t2 != r.th[k]);
-            r.th[k] = t2;
-            sincos_bounded(t2, sn[k], cs[k]);
-        }
+        if (moving) motion_particle(key, (uint64_t)i * n + j, mo, smallTurn, r.x[k], r.y[k], r.z[k], r.th[k], sn[k], cs[k]);
         // pfMeasurement.c:142-147
         const float dx = tx - r.x[k], dy = ty - r.y[k], dz = tz - r.z[k];
         const float pRange = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -265,15 +389,19 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDim
 
     // _resampleBcn(force = 0) of this row; the normalisation stays pending in rowScale.  The row sum that
     // pfMeasurement.c:148-150 multiplies into the tag particle's weight is the total of the same reduction.
-    const SmallDecision d = small_filter_update(r, sn, cs, j0, n, L, key, (uint64_t)i * n, (uint64_t)i, st.range, st.stdRange, true,
-                                                false, tx, ty, tz, true, rowSum + (size_t)f * D.nTag + i);
+    float* const rsOut = rowSum + (size_t)f * D.nTag + i;
+    SmallDecision d;
+    if (moving)
+        d = small_filter_update(r, sn, cs, j0, n, L, key, (uint64_t)i * n, (uint64_t)i, st.range, st.stdRange, true, false, tx, ty, tz,
+                                true, rsOut);
+    else
+        d = small_filter_update_lazy_theta(r, P.bcn[4] + base, j0, n, L, key, (uint64_t)i * n, (uint64_t)i, st.range, st.stdRange,
+                                           tx, ty, tz, rsOut);
     row_store1(P.bcn[0], base, j0, n, r.w);
     if (moving || d.resample) {
         row_store1(P.bcn[1], base, j0, n, r.x);
         row_store1(P.bcn[2], base, j0, n, r.y);
         row_store1(P.bcn[3], base, j0, n, r.z);
-        row_store1(P.bcn[4], base, j0, n, r.th);
-    } else if (thetaChanged) {
         row_store1(P.bcn[4], base, j0, n, r.th);
     }
     if (threadIdx.x == 0) {
