@@ -180,6 +180,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", dest="n", type=int, default=16000000, help="particles per GPU")
+    ap.add_argument("--total-particles", type=int, default=0,
+                    help="strong scaling (BASELINE config 4: 67108864): total particles of the filter, split over the GPUs; "
+                         "overrides --particles")
     ap.add_argument("--force-branch", type=int, default=-1, help="-1 reference test, 0 never resample, 1 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="timed region without per-kernel HIP events (no roofline)")
@@ -222,6 +225,8 @@ def main():
         return
 
     from slam3d_amd import particlefilter as pfm
+    if args.total_particles > 0:
+        args.n = args.total_particles // world
     K, W, n = args.steps, args.warmup, args.n
     bx, truth, rng = scene(K + W + 1)
 
@@ -323,7 +328,7 @@ def main():
             "metric": "particle-updates/sec (range update+resample) at N=16M",
             "value": 2.0 * n * world * K / dt, "unit": "particle-updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.total_particles > 0 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config3: single-tag particleFilterLoc, 8 beacons, per step depositVio + depositRange "
                                    "+ depositRssi (2 deposits = 2N particle-updates)",
