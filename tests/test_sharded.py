@@ -121,3 +121,45 @@ def test_sharded_gpu_ranks_match_single_gpu(world, pose_every):
     shards = _run(world, "gpu", n, steps, pose_every=pose_every)
     _compare(shards, ref, poses, np.array(branches), n, tol=1e-6)
     assert max(int(s["moved"][-1]) for s in shards) > 0
+
+
+def test_exchange_plan_random_boundaries():
+    """Property test of the shipping plan on random shard boundaries and offspring boundaries: every global offspring
+    index ends up in exactly one place; a sender's staging slices are contiguous (below-range first) and the receiver's
+    landing offsets tile [0, lo) and [lo, lo + n - hi) without gaps -- the layout k_loc_deposit_sharded writes and
+    k_loc_land reads (record k = local element k for k < lo, else hi + (k - lo))."""
+    from slam3d_amd.sharded import exchange_plan, shard_bounds
+    rs = np.random.RandomState(11)
+    for _ in range(300):
+        G = int(rs.randint(1, 9))
+        n = int(rs.randint(G, 5000))
+        T = shard_bounds(n, G)
+        cuts = np.sort(rs.randint(0, n + 1, size=G - 1)) if G > 1 else np.array([], dtype=int)
+        if rs.rand() < 0.3 and G > 1:                       # extreme: everything produced by one shard
+            k = int(rs.randint(0, G))
+            cuts = np.array([0] * k + [n] * (G - 1 - k))
+        F = [0] + [int(c) for c in cuts] + [n]
+        owner = np.full(n, -1)
+        for g in range(G):
+            sends, recvs, below = exchange_plan(F, T, g)
+            lo = min(max(F[g], T[g]), T[g + 1]) - T[g]
+            hi = max(max(min(F[g + 1], T[g + 1]), T[g]) - T[g], lo)
+            nloc = T[g + 1] - T[g]
+            # own production
+            owner[T[g] + lo: T[g] + hi] = g
+            # staging: contiguous from 0, below-range messages first
+            pos = 0
+            for peer, off, cnt in sorted(sends, key=lambda s_: s_[1]):
+                assert off == pos and cnt > 0
+                pos += cnt
+            assert pos == (F[g + 1] - F[g]) - (hi - lo)
+            assert below == sum(c for p, _, c in sends if p < g)
+            # landing: records tile [0, lo) then [lo, lo + nloc - hi)
+            land = sorted((off if off < lo else lo + (off - hi), cnt, off) for _, off, cnt in recvs)
+            pos = 0
+            for loff, cnt, off in land:
+                assert loff == pos
+                assert off + cnt <= lo or off >= hi          # a message never straddles the own range
+                pos += cnt
+            assert pos == lo + (nloc - hi)
+        assert (owner >= 0).sum() == sum(max(0, min(F[g + 1], T[g + 1]) - max(F[g], T[g])) for g in range(G))
