@@ -600,3 +600,71 @@ def test_full_size_16m_against_oracle(pfm, ora):
     q = np.linspace(0.01, 0.99, 25)
     for c in range(1, 4):
         assert np.abs(np.quantile(got[c][::16], q) - np.quantile(exp[c][::16], q)).max() < 0.02
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_deferred_state_machine_fuzz(pfm, seed):
+    """Random sequences of everything the API offers (deposits, pose queries, downloads, uploads, stage-by-stage calls,
+    forced branches, resets) applied to a deferred and an undeferred filter: whatever interrupts a pending resampling
+    must materialise it first, so the two must stay bit-identical throughout."""
+    rs = np.random.RandomState(1000 + seed)
+    n = int(rs.choice([1, 37, 1024, 1025, 4099, 70001]))
+    a = pfm.DeviceParticleFilterLoc(n, seed=SEED + seed)
+    b = pfm.DeviceParticleFilterLoc(n, seed=SEED + seed)
+    b.set_deferred(False)
+    both = (a, b)
+    t, pos = 1.0, np.zeros(3)
+
+    def same_state():
+        for c, (u, v) in enumerate(zip(a.download(), b.download())):
+            assert np.array_equal(u, v, equal_nan=True), f"array {c}"
+
+    for step in range(60):
+        op = rs.choice(["vio", "range", "range", "range", "rssi", "rssi", "pose", "download", "force", "stage", "upload", "reset",
+                        "stats"])
+        if op == "vio":
+            t += 0.1
+            pos = pos + rs.normal(0, 0.05, 3)
+            for f in both:
+                f.depositVio(t, float(pos[0]), float(pos[1]), float(pos[2]), 0.0)
+        elif op in ("range", "rssi"):
+            bx, by, bz = (float(v) for v in rs.uniform(-5, 5, 3))
+            rng = float(rs.uniform(0.5, 8.0))
+            for f in both:
+                if op == "range":
+                    f.depositRange(bx, by, bz, rng, 0.1)
+                else:
+                    f.depositRssi(bx, by, bz, -60)
+        elif op == "pose":
+            pa, pb = a.getTagLoc(), b.getTagLoc()
+            assert pa[0] == pb[0]
+            if pa[0]:
+                assert np.allclose(np.array(pa[2:], dtype=np.float64), np.array(pb[2:], dtype=np.float64), atol=1e-6, equal_nan=True)
+        elif op == "download":
+            same_state()
+        elif op == "force":
+            fb = int(rs.choice([-1, -1, 0, 1]))
+            for f in both:
+                f.set_force_branch(fb)
+        elif op == "stage" and a.initialized:
+            which = rs.choice(["vio", "range", "resample"])
+            for f in both:
+                if which == "vio":
+                    f.apply_vio(0.1, 0.02, -0.01, 0.0, 0.03)
+                elif which == "range":
+                    f.apply_range(1.0, -2.0, 0.5, 3.0, 0.2)
+                else:
+                    f.resample(1.0, -2.0, 0.5, 3.0, 0.2)
+        elif op == "upload" and a.initialized:
+            w, x, y, z, th = a.download()
+            w = (w * rs.uniform(0.2, 1.0, n)).astype(np.float32)
+            for f in both:
+                f.upload(w, x, y, z, th)
+        elif op == "reset":
+            for f in both:
+                f.reset(SEED + 17 * step, 0)
+        elif op == "stats" and a.initialized:
+            sa, sb = a.last_stats(), b.last_stats()
+            assert int(sa["branch"]) == int(sb["branch"])
+    same_state()
+    assert np.array_equal(a.branch_log()[0], b.branch_log()[0])
