@@ -916,9 +916,12 @@ extern "C" int pfx_loc_shard_finish(pfx_loc* pf, int pieces, int64_t lo, int64_t
 {
     clear_error();
     if (shard_ready(pf, "pfx_loc_shard_finish")) return -2;
-    if (!pieces) return launch_decide(pf, pf->shArg[3], true);
-    if (lo < 0 || hi < lo || hi > pf->n) { set_error("pfx_loc_shard_finish: [%lld, %lld) is not a range of the shard", (long long)lo, (long long)hi); return -2; }
+    if (pieces && (lo < 0 || hi < lo || hi > pf->n)) {
+        set_error("pfx_loc_shard_finish: [%lld, %lld) is not a range of the shard", (long long)lo, (long long)hi);
+        return -2;
+    }
     DeviceGuard g(pf->device);
+    if (!pieces) return launch_decide(pf, pf->shArg[3], true);
     return launch_decide(pf, pf->shArg[3], true, true, (int)lo, (int)hi);
 }
 
