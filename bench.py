@@ -320,6 +320,12 @@ def main():
                     "variant": dominant, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": d["frac"], "traffic": traffic, "avg_launch_ms": d["avg_ms"], "launches": d["launches"],
                     "alg_bytes_per_particle": d["alg_bytes_per_particle"]}
+            if traffic:
+                roof["dram_GBs"] = traffic / (d["avg_ms"] * 1e-3) / 1e9      # what the kernel really moves per second
+            if dominant.startswith("resample_"):
+                roof["note"] = ("one launch does the reference's resample (40 algorithmic B/particle) and the next deposit's "
+                                "streaming pass (44 / 28) while moving ~40.6 B; this side of the kernel is limited by "
+                                "vector-ALU issue (SQ counters: 466 VALU instructions per offspring, ~99 % busy), not by HBM")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
