@@ -256,6 +256,9 @@ def main():
     barrier()
 
     if not args.no_kernel_events:
+        # the O(N) kernels only: the two tiny prefix / decision launches of every deposit are not reported, and timing
+        # them too costs ~12 us of GPU time per step
+        pf.profile_only("stream", "stream_static", "resample", "deposit", "deposit_static")
         pf.profile_begin(4 * K * 4 + 16)
     barrier()
     t0 = time.perf_counter()

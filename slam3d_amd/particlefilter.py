@@ -225,6 +225,11 @@ class DeviceParticleFilterLoc:
     def profile_begin(self, max_records: int = 4096):
         check(self._L.pfx_loc_profile_begin(self._h, int(max_records)), "pfx_loc_profile_begin")
 
+    def profile_only(self, *kinds: str):
+        """time only these kernel classes (names from KINDS); no argument = all"""
+        mask = 0xFFFFFFFF if not kinds else sum(1 << self.KINDS.index(k) for k in kinds)
+        check(self._L.pfx_loc_profile_mask(self._h, mask), "pfx_loc_profile_mask")
+
     KINDS = ["stream", "decide", "resample", "spawn", "pose", "stream_static", "deposit", "deposit_static"]
 
     def profile_records(self, cap: int = 1 << 16):

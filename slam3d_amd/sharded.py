@@ -190,6 +190,11 @@ class GpuShard:
     def profile_begin(self, max_records):
         self._lib.check(self._L.pfx_loc_profile_begin(self._h, int(max_records)), "pfx_loc_profile_begin")
 
+    def profile_only(self, *kinds):
+        from .particlefilter import DeviceParticleFilterLoc as D
+        mask = 0xFFFFFFFF if not kinds else sum(1 << D.KINDS.index(k) for k in kinds)
+        self._lib.check(self._L.pfx_loc_profile_mask(self._h, mask), "pfx_loc_profile_mask")
+
     def profile_records(self, cap=1 << 16):
         kind = np.empty(cap, dtype=np.int32)
         ms = np.empty(cap, dtype=np.float32)
@@ -356,6 +361,9 @@ class ShardedLocFilter:
 
     def profile_begin(self, max_records):
         self.shard.profile_begin(max_records)
+
+    def profile_only(self, *kinds):
+        self.shard.profile_only(*kinds)
 
     def profile_records(self):
         return self.shard.profile_records()
