@@ -185,6 +185,8 @@ def main():
                          "overrides --particles")
     ap.add_argument("--force-branch", type=int, default=-1, help="-1 reference test, 0 never resample, 1 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-stride", type=int, default=3,
+                    help="time every n-th launch of each O(N) kernel class (3: coprime with the 8-beacon cycle of the scene)")
     ap.add_argument("--no-kernel-events", action="store_true", help="timed region without per-kernel HIP events (no roofline)")
     ap.add_argument("--pose-every-step", action="store_true", help="also call getTagLoc after every depositVio (driver pattern)")
     ap.add_argument("--undeferred", action="store_true", help="one resample kernel per deposit (pfx_loc_set_deferred(0))")
@@ -259,6 +261,7 @@ def main():
         # the O(N) kernels only: the two tiny prefix / decision launches of every deposit are not reported, and timing
         # them too costs ~12 us of GPU time per step
         pf.profile_only("stream", "stream_static", "resample", "deposit", "deposit_static")
+        pf.profile_stride(args.event_stride)     # every event_stride-th launch of a class carries events (~3 us each)
         pf.profile_begin(4 * K * 4 + 16)
     barrier()
     t0 = time.perf_counter()
@@ -298,8 +301,11 @@ def main():
             if not sel.shape[0]:
                 continue
             prev = None
-            if full_log is not None and full_log.shape[0] >= 2 * K + 1 and sel.shape[0] == K:
-                prev = full_log[-(2 * K + 1):-1][phase::2].astype(bool)      # decision before each deposit of this phase
+            if full_log is not None and full_log.shape[0] >= 2 * K + 1:
+                # decision before each deposit of this phase; the timed launches are number 0, stride, 2 * stride ... of them
+                cand = full_log[-(2 * K + 1):-1][phase::2][::args.event_stride].astype(bool)
+                if cand.shape[0] == sel.shape[0]:
+                    prev = cand
             if prev is None:
                 prev = sel > 0.5 * (sel.min() + sel.max())
             classes[fused] = sel[prev]

@@ -100,6 +100,8 @@ int      pfx_resample_indices_f64(const double* cdf, int64_t n, double rStart, d
 int      pfx_loc_profile_begin(pfx_loc* pf, int max_records);
 /* which kernel classes are timed (bit k = PFX_K_* class k; default all): a timed launch costs ~3 us of GPU time */
 int      pfx_loc_profile_mask(pfx_loc* pf, unsigned mask);
+/* time only every stride-th launch of a class (launch 0, stride, 2 * stride ... counted from pfx_loc_profile_begin) */
+int      pfx_loc_profile_stride(pfx_loc* pf, int stride);
 /* sums of elapsed ms and launch counts per kernel class since pfx_loc_profile_begin; stops recording */
 int      pfx_loc_profile_read(pfx_loc* pf, double ms[PFX_K_COUNT], int64_t launches[PFX_K_COUNT]);
 /* the same records one by one, in launch order (call before pfx_loc_profile_read, which clears them);

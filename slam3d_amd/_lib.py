@@ -78,6 +78,7 @@ def lib() -> C.CDLL:
     sig("pfx_resample_indices_f64", i, vp, i64, d, d, vp, i)
     sig("pfx_loc_profile_begin", i, vp, i)
     sig("pfx_loc_profile_mask", i, vp, C.c_uint)
+    sig("pfx_loc_profile_stride", i, vp, i)
     sig("pfx_loc_profile_read", i, vp, pd_, C.POINTER(i64))
     sig("pfx_loc_profile_records", i64, vp, vp, vp, i64)
     sig("pfx_loc_branch_log", i64, vp, vp, i64, C.POINTER(i64))

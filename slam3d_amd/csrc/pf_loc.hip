@@ -135,6 +135,8 @@ struct pfx_loc {
     size_t profUsed = 0;
     bool profOn = false;
     unsigned profMask = ~0u;        // kernel classes that are timed while profOn
+    int profStride = 1;             // ... every profStride-th launch of a class (the first one after profile_begin included)
+    long long profCount[PFX_K_COUNT] = {};
 };
 
 static std::mutex g_mu;
@@ -156,7 +158,8 @@ struct ProfScope {
     ProfRec* r = nullptr;
     ProfScope(pfx_loc* pf, int kind)
     {
-        if (pf->profOn && ((pf->profMask >> kind) & 1u) && pf->profUsed < pf->prof.size()) {
+        if (pf->profOn && ((pf->profMask >> kind) & 1u) && (pf->profCount[kind]++ % pf->profStride) == 0 &&
+            pf->profUsed < pf->prof.size()) {
             r = &pf->prof[pf->profUsed++];
             r->kind = kind;
         }
@@ -983,6 +986,7 @@ extern "C" int pfx_loc_profile_begin(pfx_loc* pf, int max_records)
         pf->prof.push_back(r);
     }
     pf->profUsed = 0;
+    for (int k = 0; k < PFX_K_COUNT; ++k) pf->profCount[k] = 0;
     pf->profOn = true;
     return 0;
 }
@@ -991,6 +995,12 @@ extern "C" int pfx_loc_profile_mask(pfx_loc* pf, unsigned mask)
 {   // bit k set: launches of kernel class k (PFX_K_*) are timed.  A timed launch carries two events on its dispatch
     // packet (~3 us of GPU time each launch at N = 16 M): time only what is asked about.
     pf->profMask = mask;
+    return 0;
+}
+
+extern "C" int pfx_loc_profile_stride(pfx_loc* pf, int stride)
+{   // time launch 0, stride, 2 * stride, ... of every class (counted from pfx_loc_profile_begin)
+    pf->profStride = stride < 1 ? 1 : stride;
     return 0;
 }
 

@@ -230,6 +230,10 @@ class DeviceParticleFilterLoc:
         mask = 0xFFFFFFFF if not kinds else sum(1 << self.KINDS.index(k) for k in kinds)
         check(self._L.pfx_loc_profile_mask(self._h, mask), "pfx_loc_profile_mask")
 
+    def profile_stride(self, stride: int):
+        """time launch 0, stride, 2*stride, ... of every class only"""
+        check(self._L.pfx_loc_profile_stride(self._h, int(stride)), "pfx_loc_profile_stride")
+
     KINDS = ["stream", "decide", "resample", "spawn", "pose", "stream_static", "deposit", "deposit_static"]
 
     def profile_records(self, cap: int = 1 << 16):

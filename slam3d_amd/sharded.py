@@ -190,6 +190,9 @@ class GpuShard:
     def profile_begin(self, max_records):
         self._lib.check(self._L.pfx_loc_profile_begin(self._h, int(max_records)), "pfx_loc_profile_begin")
 
+    def profile_stride(self, stride):
+        self._lib.check(self._L.pfx_loc_profile_stride(self._h, int(stride)), "pfx_loc_profile_stride")
+
     def profile_only(self, *kinds):
         from .particlefilter import DeviceParticleFilterLoc as D
         mask = 0xFFFFFFFF if not kinds else sum(1 << D.KINDS.index(k) for k in kinds)
@@ -364,6 +367,9 @@ class ShardedLocFilter:
 
     def profile_only(self, *kinds):
         self.shard.profile_only(*kinds)
+
+    def profile_stride(self, stride):
+        self.shard.profile_stride(stride)
 
     def profile_records(self):
         return self.shard.profile_records()
