@@ -39,6 +39,12 @@ enum { PFX_K_STREAM = 0,        /* k_loc_stream with VIO motion (reads and write
 const char* pfx_version(void);
 const char* pfx_last_error(void);                   /* thread-local, "" if none */
 int         pfx_device_count(void);                 /* gfx950 devices visible; 0 = none (every create fails) */
+/* What the reference-layout entry points (particleFilterLoc_*, particleFilterSlam_*: void, no error channel in the
+ * reference) do when the GPU side fails or a struct is not bound.  1 (default): print the message and abort() -- a
+ * failure must not pass for a result.  0: keep the message for pfx_last_error(), count it, and return with the call
+ * having had no effect (get*Loc return 0). */
+void        pfx_set_abort_on_error(int enable);
+long long   pfx_error_count(void);                  /* failures swallowed since the process started (mode 0 only) */
 
 /* ---- runtime-N Loc filter ---- */
 /* particleFilterLoc_init with a particle count and placement chosen at run time
@@ -91,8 +97,11 @@ int      pfx_loc_record_ancestors(pfx_loc* pf, int enable);  /* keep the ancesto
 int      pfx_loc_last_ancestors(pfx_loc* pf, int32_t* anc, int64_t n);
 
 /* systematic-resample index selection on a caller-supplied CDF (host arrays), as pfResample.c:70-72
- * walks it: anc[i] = first j with rStart + rStep*i < cdf[j], clamped to n-1.  Runs the same device
- * search the resample kernel uses.  Bit-exact against the reference loop for identical inputs. */
+ * walks it: anc[i] = first j with rStart + rStep*i < cdf[j], clamped to n-1.  _f32 evaluates the
+ * reference's float32 expression (no fused multiply-add) and is bit-exact against the reference loop
+ * for identical inputs.  These two run a plain binary search over the caller's array in global memory;
+ * the filter's own resampling (tile CDFs rebuilt in LDS, integer offsets) is checked index for index
+ * through pfx_loc_record_ancestors / pfx_loc_last_ancestors. */
 int      pfx_resample_indices_f32(const float* cdf, int64_t n, float rStart, float rStep, int32_t* anc, int device);
 int      pfx_resample_indices_f64(const double* cdf, int64_t n, double rStart, double rStep, int32_t* anc, int device);
 

@@ -221,8 +221,8 @@ class OracleLoc:
     def last_stats(self):
         buf = (C.c_double * 12)()
         lib().ora_loc_last_stats(self.h, buf)
-        keys = ["branch", "numSpawn", "s", "ss", "csum", "ssum", "ess", "htheta", "rStart", "rStep", "m"]
-        return dict(zip(keys, list(buf)[:11]))
+        keys = ["branch", "numSpawn", "s", "ss", "csum", "ssum", "ess", "htheta", "rStart", "rStep", "m", "S"]
+        return dict(zip(keys, list(buf)[:12]))
 
     def last_ancestors(self):
         return _view(lib().ora_loc_last_ancestors(self.h), self.n).copy()

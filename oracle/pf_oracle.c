@@ -284,6 +284,15 @@ static void spawn_from_other(soa_t* dst, size_t i, const soa_t* src, size_t j, o
 
 typedef struct { float s, ss, csum, ssum; double S; } wsums_t;
 
+/* ORA_ACC_F64 (the rule of the HIP path; no counterpart in the reference): a weight enters every
+ * weight total and every CDF rounded to the nearest multiple of 2^-20 (ties to even), and those are added in double.
+ * Multiples of 2^-20 totalling less than 2^33 add up exactly in double, so the order of the additions -- serial
+ * here, by tiles, chunks and shards on the GPU -- cannot change a single bit of the CDF. */
+float ora_cdf_weight(float w)
+{
+    return rintf(w * 1048576.0f) * 9.5367431640625e-07f;
+}
+
 /* pfResample.c:37-50 (and :93-106, :151-164): weight sums + inclusive CDF.  ORA_ACC_F32 keeps the
  * reference's serial float running sums; ORA_ACC_F64 forms the same float products but adds them in
  * double (the rule of the HIP path), rounding the four totals to float afterwards. */
@@ -305,7 +314,7 @@ static void weight_pass(const float* w, const float* th, int n, int acc, double*
         for (int i = 0; i < n; ++i) {
             float wi = w[i];
             float p2 = wi * wi, pc = wi * cosf(th[i]), ps = wi * sinf(th[i]);
-            s += wi; ss += p2; cs += pc; sn += ps;
+            s += ora_cdf_weight(wi); ss += p2; cs += pc; sn += ps;
             cdf[i] = s;
         }
         o->s = (float)s; o->ss = (float)ss; o->csum = (float)cs; o->ssum = (float)sn; o->S = s;
@@ -348,7 +357,7 @@ void ora_resample_indices_f64(const double* cdf, int n, double rStart, double rS
 typedef struct {
     int branch, numSpawn;
     float s, ss, csum, ssum, ess, htheta, m;
-    double rStart, rStep;
+    double rStart, rStep, S;
 } rs_stats_t;
 
 /* Number of offspring that fell off the end of the CDF (rStart + rStep*i >= cdf[n-1]) and were
@@ -378,6 +387,7 @@ static void resample_block(soa_t* p, size_t off, int n, soa_t* buf, double* cdf,
 
     memset(st, 0, sizeof(*st));
     st->s = s; st->ss = ws.ss; st->csum = ws.csum; st->ssum = ws.ssum; st->ess = ess; st->numSpawn = numSpawn;
+    st->S = ws.S;
 
     if (ess * invN < RESAMPLE_THRESH || numSpawn > 0 || force) {
         float htheta = theta_bandwidth(ws.csum, ws.ssum, s, ess);
@@ -438,7 +448,7 @@ static void pose_estimate(const soa_t* p, int n, int acc, const vio_t* v,
             float w = p->w[i];
             float px = w * p->x[i], py = w * p->y[i], pz = w * p->z[i];
             float pc = w * cosf(p->th[i]), ps = w * sinf(p->th[i]);
-            S += w; X += px; Y += py; Z += pz; C += pc; Sn += ps;
+            S += ora_cdf_weight(w); X += px; Y += py; Z += pz; C += pc; Sn += ps;
         }
         s = (float)S; xs = (float)X; ys = (float)Y; zs = (float)Z; cs = (float)C; sn = (float)Sn;
     }
@@ -632,7 +642,7 @@ void ora_loc_last_stats(const ora_loc* pf, double out[12])
 {
     const rs_stats_t* s = &pf->st;
     out[0] = s->branch; out[1] = s->numSpawn; out[2] = s->s; out[3] = s->ss; out[4] = s->csum; out[5] = s->ssum;
-    out[6] = s->ess; out[7] = s->htheta; out[8] = s->rStart; out[9] = s->rStep; out[10] = s->m; out[11] = 0;
+    out[6] = s->ess; out[7] = s->htheta; out[8] = s->rStart; out[9] = s->rStep; out[10] = s->m; out[11] = s->S;
 }
 const int* ora_loc_last_ancestors(const ora_loc* pf) { return pf->anc; }
 const double* ora_loc_last_cdf(const ora_loc* pf) { return pf->cdf; }
@@ -724,7 +734,7 @@ static void slam_apply_range(ora_slam* pf, ora_bcn* b, float range, float stdRan
             float pRange = sqrtf(dx * dx + dy * dy + dz * dz);
             if (fabsf(pRange - range) > 3 * stdRange)
                 b->p.w[k] *= minWeight;
-            sum32 += b->p.w[k]; sum64 += b->p.w[k];
+            sum32 += b->p.w[k]; sum64 += ora_cdf_weight(b->p.w[k]);
         }
         pf->p.w[i] *= (pf->acc == ORA_ACC_F32) ? sum32 : (float)sum64;
     }
@@ -831,13 +841,13 @@ int ora_slam_get_bcn_loc(const ora_slam* pf, const ora_bcn* b, double* t, float*
                 float w2 = b->p.w[k];
                 float px = w2 * b->p.x[k], py = w2 * b->p.y[k], pz = w2 * b->p.z[k];
                 float pc = w2 * cosf(b->p.th[k]), ps = w2 * sinf(b->p.th[k]);
-                S2 += w2; X2 += px; Y2 += py; Z2 += pz; C2 += pc; N2 += ps;
+                S2 += ora_cdf_weight(w2); X2 += px; Y2 += py; Z2 += pz; C2 += pc; N2 += ps;
             }
             s2 = (float)S2; x2 = (float)X2; y2 = (float)Y2; z2 = (float)Z2; c2 = (float)C2; n2 = (float)N2;
         }
         float tx = w1 * x2 / s2, ty = w1 * y2 / s2, tz = w1 * z2 / s2, tc = w1 * c2 / s2, tn = w1 * n2 / s2;
         s1 += w1; x1 += tx; y1 += ty; z1 += tz; c1 += tc; n1 += tn;
-        S1 += w1; X1 += tx; Y1 += ty; Z1 += tz; C1 += tc; N1 += tn;
+        S1 += ora_cdf_weight(w1); X1 += tx; Y1 += ty; Z1 += tz; C1 += tc; N1 += tn;
     }
     if (pf->acc != ORA_ACC_F32) {
         s1 = (float)S1; x1 = (float)X1; y1 = (float)Y1; z1 = (float)Z1; c1 = (float)C1; n1 = (float)N1;

@@ -21,6 +21,11 @@
  *   - an optional "f64 accumulation" rule (ORA_ACC_F64) for the weight sums
  *     and the CDF: this is the rule the HIP kernels implement, because the
  *     reference's serial f32 running sum is numerically void for N >= 2^24.
+ *     Under it a weight enters every weight total and every CDF rounded to the
+ *     nearest multiple of 2^-20 (ora_cdf_weight) and the sums are double: such
+ *     sums are exact below 2^33, hence independent of the order of the
+ *     additions, which is what lets the GPU's tiled / sharded / deferred sums
+ *     and this file's serial loops agree on every CDF value bit for bit.
  *     ORA_ACC_F32 is the faithful reference arithmetic.
  */
 #ifndef PF_ORACLE_H
@@ -89,6 +94,9 @@ void     ora_offspring_block(ora_rng* rng, uint32_t stream, uint32_t epoch, int6
                              float* ox, float* oy, float* oz, float* oth);
 void     ora_decide(ora_rng* rng, uint32_t stream, uint32_t epoch, double S, double SS, double C, double SN, int64_t n,
                     float range, int force, double out[6]);
+
+/* the weight as it enters a weight total / the CDF under ORA_ACC_F64: nearest multiple of 2^-20, ties to even */
+float ora_cdf_weight(float w);
 
 /* systematic-resample index selection exactly as pfResample.c:70-72 walks it, on a caller CDF */
 long ora_clamp_events(void);   /* offspring clamped to the last ancestor so far (reference: out-of-bounds read) */

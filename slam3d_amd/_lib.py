@@ -46,6 +46,8 @@ def lib() -> C.CDLL:
     sig("pfx_version", C.c_char_p)
     sig("pfx_last_error", C.c_char_p)
     sig("pfx_device_count", i)
+    sig("pfx_set_abort_on_error", None, i)
+    sig("pfx_error_count", C.c_longlong)
     sig("pfx_loc_create", vp, i64, u32, u32, i)
     sig("pfx_loc_destroy", None, vp)
     sig("pfx_loc_reset", i, vp, u32, u32)

@@ -30,6 +30,25 @@ constexpr float kHxyz = 0.1f;
 
 enum : uint32_t { P_VIO = 1, P_RSTART = 2, P_JITTER = 3, P_SPAWN = 4 };
 
+// ---------------------------------------------------------------- weights as they enter a sum
+// CDF rule (oracle/pf_oracle.c cdf_weight): a weight enters every weight total and every CDF rounded
+// to the nearest multiple of 2^-20, and those are added in float64.  Multiples of 2^-20 that total less than 2^33
+// add up EXACTLY in float64, whatever the order: the tile / chunk / shard / piece structure of the sums below, the
+// deferred and the undeferred path, one GPU or sixteen all produce the same CDF bit for bit, and so does the
+// oracle's plain sequential loop.  (The reference's serial float32 sum, pfResample.c:45,49, resolves 2^-10 at
+// N = 10 000 and nothing at all past 2^24.)  Three full-rate float32 instructions per particle.
+constexpr float kCdfScale = 1048576.0f;                     // 2^20
+constexpr float kCdfInvScale = 9.5367431640625e-07f;        // 2^-20
+constexpr double kCdfExactBelow = 8589934592.0;             // 2^33: totals below this are exact
+// tiles whose weight total stays below this have their CDF offsets in 32-bit integers (units of 2^-20)
+constexpr double kTileU32Below = 4095.0;
+
+__host__ __device__ __forceinline__ float cdf_units(float w)
+{   // the weight in units of 2^-20, an integer-valued float (round to nearest even: v_rndne_f32 / rintf)
+    return __builtin_rintf(w * kCdfScale);
+}
+__host__ __device__ __forceinline__ float cdf_weight(float w) { return cdf_units(w) * kCdfInvScale; }
+
 // ---------------------------------------------------------------- Philox4x32-10
 struct u32x4 { uint32_t a, b, c, d; };
 
@@ -378,6 +397,94 @@ __device__ __forceinline__ int upper_bound_tile(const double* cdf, int n, double
 #pragma unroll
     for (int step = kTile / 2; step >= 1; step >>= 1) pos += (u < cdf[pos + step - 1]) ? 0 : step;
     return pos < n ? pos : n - 1;
+}
+
+// ---------------------------------------------------------------- the same selection on 32-bit offsets
+// Inside a tile whose weight total is below kTileU32Below the CDF is held as integer offsets from the tile's start
+// value T, in units of 2^-20 (exact: every CDF value is a multiple of 2^-20).  For an offspring position u >= T,
+// u - T is exact in float64 and  u < CDF(j)  <=>  floor((u - T) * 2^20) < offset(j),  so the integer search below
+// returns exactly what upper_bound_tile returns on the float64 table -- at full-rate 32-bit compares and half the
+// LDS bytes.
+__device__ __forceinline__ uint32_t cvt_u32_sat(double v)
+{   // v_cvt_u32_f64: truncates, saturates to [0, 2^32 - 1], NaN -> 0 (a C++ cast is undefined outside the range)
+    uint32_t r;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ uint32_t cvt_u32_sat(float v)
+{
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+__device__ __forceinline__ int upper_bound_tile_u32(const uint32_t* tab, int n, uint32_t d)
+{   // entries from n on hold 0xFFFFFFFF
+    int pos = 0;
+#pragma unroll
+    for (int step = kTile / 2; step >= 1; step >>= 1) pos += (d < tab[pos + step - 1]) ? 0 : step;
+    return pos < n ? pos : n - 1;
+}
+
+// Inclusive scan of one 32-bit integer per thread across a 256-thread block (exact, any order).  `lds` holds 4 words.
+__device__ __forceinline__ uint32_t block_inclusive_scan_u32(uint32_t v, uint32_t* lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(v, off, 64);
+        if (lane >= off) v += up;
+    }
+    if (lane == 63) lds[wave] = v;
+    __syncthreads();
+    uint32_t pre = 0;
+    if (wave > 0) pre = lds[0];
+    if (wave > 1) pre += lds[1];
+    if (wave > 2) pre += lds[2];
+    return v + pre;
+}
+
+// One tile's CDF in LDS, in whichever of the two forms its total allows.  `tab` holds kTile doubles (the integer
+// form uses the first half of it), `red` 4 doubles.  w: the thread's four weights (elements 4 * tid .. + 3 of the
+// tile), tileStart / tileEnd: CDF value before the tile's first / after its last particle, nValid: particles of the
+// tile that exist.  Returns true (uniformly over the workgroup) if the integer form was built.  Ends with a barrier.
+__device__ __forceinline__ bool build_tile_cdf(const float (&w)[4], double tileStart, double tileEnd, double grandTotal,
+                                               int nValid, double* tab, double* red)
+{
+    const int tid = threadIdx.x;
+    const bool small = (tileEnd - tileStart < kTileU32Below) && (grandTotal < kCdfExactBelow);     // NaN: false
+    if (small) {
+        uint32_t* const tab32 = reinterpret_cast<uint32_t*>(tab);
+        const uint32_t a0 = cvt_u32_sat(cdf_units(w[0])), a1 = a0 + cvt_u32_sat(cdf_units(w[1]));
+        const uint32_t a2 = a1 + cvt_u32_sat(cdf_units(w[2])), a3 = a2 + cvt_u32_sat(cdf_units(w[3]));
+        const uint32_t off = block_inclusive_scan_u32(a3, reinterpret_cast<uint32_t*>(red)) - a3;
+        uint4 o;
+        o.x = (tid * 4 + 0 < nValid) ? off + a0 : 0xFFFFFFFFu;
+        o.y = (tid * 4 + 1 < nValid) ? off + a1 : 0xFFFFFFFFu;
+        o.z = (tid * 4 + 2 < nValid) ? off + a2 : 0xFFFFFFFFu;
+        o.w = (tid * 4 + 3 < nValid) ? off + a3 : 0xFFFFFFFFu;
+        *reinterpret_cast<uint4*>(tab32 + tid * 4) = o;
+    } else {
+        // pfResample.c:45,49 in double: tile start + inclusive scan
+        const double a0 = cdf_weight(w[0]), a1 = a0 + cdf_weight(w[1]), a2 = a1 + cdf_weight(w[2]), a3 = a2 + cdf_weight(w[3]);
+        double total;
+        const double incl = block_inclusive_scan(a3, red, total);
+        const double off = tileStart + (incl - a3);
+        const double inf = __builtin_huge_val();            // pad entries of the last tile: never selected
+        tab[tid * 4 + 0] = (tid * 4 + 0 < nValid) ? off + a0 : inf;
+        tab[tid * 4 + 1] = (tid * 4 + 1 < nValid) ? off + a1 : inf;
+        tab[tid * 4 + 2] = (tid * 4 + 2 < nValid) ? off + a2 : inf;
+        tab[tid * 4 + 3] = (tid * 4 + 3 < nValid) ? off + a3 : inf;
+    }
+    __syncthreads();
+    return small;
+}
+
+// ancestor of the offspring at CDF position u inside the tile whose table build_tile_cdf left in `tab`
+__device__ __forceinline__ int tile_ancestor(const double* tab, bool small, int nValid, double tileStart, double u)
+{
+    if (small) return upper_bound_tile_u32(reinterpret_cast<const uint32_t*>(tab), nValid, cvt_u32_sat((u - tileStart) * (double)kCdfScale));
+    return upper_bound_tile(tab, nValid, u);
 }
 
 }  // namespace pf

@@ -18,6 +18,15 @@ void clear_error();
 // memory).  Failing silently -- or falling back to some CPU path -- would hide that the HIP path is
 // not the one running, so the reference-layout entry points abort loudly instead.
 [[noreturn]] void die(const char* what);
+// The same report for callers that would rather survive it: after pfx_set_abort_on_error(0) the message stays in
+// pfx_last_error(), pfx_error_count() goes up by one and fail() RETURNS -- the entry point then returns at once, the
+// call having had no effect.  Default (and whenever the mode is 1): die().
+void fail(const char* what);
+
+// Philox key word 1 of the next filter initialised through the reference-layout API: a process-wide counter that
+// particleFilterSeed_set puts back to 0, so that "set the seed, initialise, run" reproduces its sample path however
+// many filters the process has initialised before (the reference reseeds its one global stream, pfRandom.c:51-60).
+uint32_t next_filter_stream();
 
 #define PF_HIP_OK(expr)                                                                         \
     do {                                                                                        \

@@ -38,7 +38,18 @@ void die(const char* what)
     fprintf(stderr, "libparticlefilter: %s: %s\nlibparticlefilter: there is no CPU fallback; aborting.\n", what, last_error_buf());
     abort();
 }
+static int g_abortOnError = 1;
+static long long g_errorCount = 0;
+void fail(const char* what)
+{
+    if (g_abortOnError) die(what);
+    ++g_errorCount;
+    fprintf(stderr, "libparticlefilter: %s: %s (call ignored)\n", what, last_error_buf());
+}
 }  // namespace pf
+
+extern "C" void pfx_set_abort_on_error(int enable) { pf::g_abortOnError = enable ? 1 : 0; }
+extern "C" long long pfx_error_count(void) { return pf::g_errorCount; }
 
 extern "C" {
 unsigned int PF_SEED = 0;       // pfRandom.c:51-52
@@ -142,6 +153,14 @@ struct pfx_loc {
 static std::mutex g_mu;
 static std::unordered_set<pfx_loc*> g_live;
 static uint32_t g_nextStream = 0;
+
+namespace pf {
+uint32_t next_filter_stream()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_nextStream++;
+}
+}  // namespace pf
 
 namespace {
 
@@ -1071,7 +1090,7 @@ pfx_loc* bound(const particleFilterLoc_t* pf)
 pfx_loc* must_be_bound(const particleFilterLoc_t* pf, const char* fn)
 {
     pfx_loc* h = bound(pf);
-    if (!h) { set_error("%s: struct %p was not initialised with particleFilterLoc_init (or was moved)", fn, (const void*)pf); die(fn); }
+    if (!h) { set_error("%s: struct %p was not initialised with particleFilterLoc_init (or was moved)", fn, (const void*)pf); fail(fn); }
     return h;
 }
 
@@ -1102,22 +1121,24 @@ void sync_scalars(particleFilterLoc_t* pf, const pfx_loc* h)
 }  // namespace
 
 extern "C" void particleFilterSeed_set(unsigned int seed)
-{   // particleFilter.c:26-30
+{   // particleFilter.c:26-30.  The reference's next draw after this call is the first of the stream of `seed`
+    // whatever happened before; here the sub-stream counter starts over for the same reason.
     PF_SEED = seed;
     PF_SEED_SET = 1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_nextStream = 0;
 }
 
 extern "C" void particleFilterLoc_init(particleFilterLoc_t* pf)
 {   // particleFilter.c:32-46 + pfRandom.c:56-60 (seed from the clock unless one was set)
     if (!PF_SEED_SET) PF_SEED = (unsigned int)time(nullptr);
-    uint32_t sid;
-    { std::lock_guard<std::mutex> lk(g_mu); sid = g_nextStream++; }
+    const uint32_t sid = next_filter_stream();
     pfx_loc* h = bound(pf);
     if (h) {
         pfx_loc_reset(h, PF_SEED, sid);
     } else {
         h = pfx_loc_create(legacy_n(), PF_SEED, sid, legacy_device());
-        if (!h) die("particleFilterLoc_init");
+        if (!h) { fail("particleFilterLoc_init"); return; }
         LocStash* s = stash_of(pf);
         s->magic = kLocMagic; s->self = (uint64_t)(uintptr_t)pf; s->handle = h;
     }
@@ -1127,6 +1148,7 @@ extern "C" void particleFilterLoc_init(particleFilterLoc_t* pf)
 extern "C" void particleFilterLoc_depositVio(particleFilterLoc_t* pf, double t, float x, float y, float z, float dist)
 {
     pfx_loc* h = must_be_bound(pf, "particleFilterLoc_depositVio");
+    if (!h) return;
     pfx_loc_deposit_vio(h, t, x, y, z, dist);
     sync_scalars(pf, h);
 }
@@ -1134,22 +1156,25 @@ extern "C" void particleFilterLoc_depositVio(particleFilterLoc_t* pf, double t, 
 extern "C" void particleFilterLoc_depositRange(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
 {
     pfx_loc* h = must_be_bound(pf, "particleFilterLoc_depositRange");
-    if (pfx_loc_deposit_range(h, bx, by, bz, range, stdRange)) die("particleFilterLoc_depositRange");
+    if (!h) return;
+    if (pfx_loc_deposit_range(h, bx, by, bz, range, stdRange)) { fail("particleFilterLoc_depositRange"); return; }
     sync_scalars(pf, h);
 }
 
 extern "C" void particleFilterLoc_depositRssi(particleFilterLoc_t* pf, float bx, float by, float bz, int rssi)
 {
     pfx_loc* h = must_be_bound(pf, "particleFilterLoc_depositRssi");
-    if (pfx_loc_deposit_rssi(h, bx, by, bz, rssi)) die("particleFilterLoc_depositRssi");
+    if (!h) return;
+    if (pfx_loc_deposit_rssi(h, bx, by, bz, rssi)) { fail("particleFilterLoc_depositRssi"); return; }
     sync_scalars(pf, h);
 }
 
 extern "C" uint8_t particleFilterLoc_getTagLoc(const particleFilterLoc_t* pf, double* t, float* x, float* y, float* z, float* theta)
 {
     pfx_loc* h = must_be_bound(pf, "particleFilterLoc_getTagLoc");
+    if (!h) return 0;
     const int rc = pfx_loc_get_tag_loc(h, t, x, y, z, theta);
-    if (rc < 0) die("particleFilterLoc_getTagLoc");
+    if (rc < 0) { fail("particleFilterLoc_getTagLoc"); return 0; }
     return (uint8_t)rc;
 }
 

@@ -126,8 +126,9 @@ __device__ __forceinline__ void stream_tile(const LocBufs& bufs, const LocCtl* _
             if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
         }
         w[k] = wi;
-        // pfResample.c:44-48 and particleFilter.c:266-272: float products, added in double
-        acc[0] += wi;
+        // pfResample.c:44-48 and particleFilter.c:266-272: float products, added in double; the weight total is the
+        // CDF's last value and takes the weight as the CDF does (cdf_weight: exact sums)
+        acc[0] += cdf_weight(wi);
         acc[1] += wi * wi;
         acc[2] += wi * cs;
         acc[3] += wi * sn;
@@ -437,35 +438,25 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, LocCtl*
     const double rStart = ctl->rStart, rStep = ctl->rStep;
     const double shardBase = ctl->shardBase, shardEnd = ctl->shardEnd;
     const double tileStart = tile_start_cdf(chunkBase, tileIncl, t, shardBase, shardEnd);
+    const double tileEnd = tile_start_cdf(chunkBase, tileIncl, t + 1, shardBase, shardEnd);
     // Offspring range [i0, i1) of this tile.  Neighbouring workgroups (and neighbouring shards) evaluate the
     // same expression for a shared boundary, so the ranges tile [outBegin, outEnd) exactly.  One lane each of
     // two different waves does the float64 division; everybody else picks the result up after the barrier.
     if (tid == 0) {
         span[0] = (t == 0) ? ctl->outBegin : first_offspring_at(tileStart, rStart, rStep, ctl->nGlobal);
     } else if (tid == 64) {
-        span[1] = (t == numTiles - 1)
-                      ? ctl->outEnd
-                      : first_offspring_at(tile_start_cdf(chunkBase, tileIncl, t + 1, shardBase, shardEnd), rStart, rStep,
-                                           ctl->nGlobal);
+        span[1] = (t == numTiles - 1) ? ctl->outEnd : first_offspring_at(tileEnd, rStart, rStep, ctl->nGlobal);
     }
 
-    // this tile's CDF, rebuilt from the weights (pfResample.c:45,49 in double): tile start + inclusive scan
-    const double a0 = w4.x, a1 = a0 + w4.y, a2 = a1 + w4.z, a3 = a2 + w4.w;
-    double total;
-    const double incl = block_inclusive_scan(a3, red, total);
-    const double off = tileStart + (incl - a3);
+    // this tile's CDF, rebuilt from the weights (pfResample.c:45,49): integer offsets from tileStart or float64 values
     const long long rem = n - tbase;
     const int nValid = rem < kTile ? (int)rem : kTile;
-    const double inf = __builtin_huge_val();            // pad entries of the last tile: never selected
-    cdf[tid * 4 + 0] = (tid * 4 + 0 < nValid) ? off + a0 : inf;
-    cdf[tid * 4 + 1] = (tid * 4 + 1 < nValid) ? off + a1 : inf;
-    cdf[tid * 4 + 2] = (tid * 4 + 2 < nValid) ? off + a2 : inf;
-    cdf[tid * 4 + 3] = (tid * 4 + 3 < nValid) ? off + a3 : inf;
+    const float wq[4] = { w4.x, w4.y, w4.z, w4.w };
     anc[tid * 4 + 0] = make_float4(x4.x, y4.x, z4.x, t4.x);
     anc[tid * 4 + 1] = make_float4(x4.y, y4.y, z4.y, t4.y);
     anc[tid * 4 + 2] = make_float4(x4.z, y4.z, z4.z, t4.z);
     anc[tid * 4 + 3] = make_float4(x4.w, y4.w, z4.w, t4.w);
-    __syncthreads();
+    const bool small = build_tile_cdf(wq, tileStart, tileEnd, ctl->S, nValid, cdf, red);
     const long long i0 = span[0], i1 = span[1];
     if (POSE && t == 0 && tid == 0) ctl->rsValid = 1;   // nobody in this launch reads it; k_loc_pose_tiles then exits
     if (i0 >= i1) {
@@ -510,7 +501,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, LocCtl*
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const double u = rStart + rStep * (dCb + (double)(k0 + m));     // pfResample.c:71 with i = cb + k
-                jj[m] = upper_bound_tile(cdf, nValid, u);
+                jj[m] = tile_ancestor(cdf, small, nValid, tileStart, u);
             }
             float ox[4], oy[4], oz[4], ot[4];
 #pragma unroll
@@ -623,33 +614,24 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
     const double rStart = ctl->rStart, rStep = ctl->rStep;
     const double shardBase = ctl->shardBase, shardEnd = ctl->shardEnd;     // [0, S) unless the filter is sharded
     const double tileStart = tile_start_cdf(chunkBase, tileIncl, t, shardBase, shardEnd);
+    const double tileEnd = tile_start_cdf(chunkBase, tileIncl, t + 1, shardBase, shardEnd);
     const long long gOff = SHARDED ? ctl->selfBegin : 0;                    // global index of local element 0
     const long long nGlobal = SHARDED ? ctl->nGlobal : n;
     const long long outBegin = SHARDED ? ctl->outBegin : 0, outEnd = SHARDED ? ctl->outEnd : n;
     if (tid == 0) {
         span[0] = (t == 0) ? outBegin : first_offspring_at(tileStart, rStart, rStep, nGlobal);
     } else if (tid == 64) {
-        span[1] = (t == numTiles - 1)
-                      ? outEnd
-                      : first_offspring_at(tile_start_cdf(chunkBase, tileIncl, t + 1, shardBase, shardEnd), rStart, rStep, nGlobal);
+        span[1] = (t == numTiles - 1) ? outEnd : first_offspring_at(tileEnd, rStart, rStep, nGlobal);
     }
 
-    const double a0 = w4.x, a1 = a0 + w4.y, a2 = a1 + w4.z, a3 = a2 + w4.w;
-    double total;
-    const double incl = block_inclusive_scan(a3, red, total);
-    const double off = tileStart + (incl - a3);
     const int rem = n - tbase;
     const int nValid = rem < kTile ? rem : kTile;
-    const double inf = __builtin_huge_val();
-    cdf[tid * 4 + 0] = (tid * 4 + 0 < nValid) ? off + a0 : inf;
-    cdf[tid * 4 + 1] = (tid * 4 + 1 < nValid) ? off + a1 : inf;
-    cdf[tid * 4 + 2] = (tid * 4 + 2 < nValid) ? off + a2 : inf;
-    cdf[tid * 4 + 3] = (tid * 4 + 3 < nValid) ? off + a3 : inf;
+    const float wq[4] = { w4.x, w4.y, w4.z, w4.w };
     anc[tid * 4 + 0] = make_float4(x4.x, y4.x, z4.x, t4.x);
     anc[tid * 4 + 1] = make_float4(x4.y, y4.y, z4.y, t4.y);
     anc[tid * 4 + 2] = make_float4(x4.z, y4.z, z4.z, t4.z);
     anc[tid * 4 + 3] = make_float4(x4.w, y4.w, z4.w, t4.w);
-    __syncthreads();
+    const bool small = build_tile_cdf(wq, tileStart, tileEnd, ctl->S, nValid, cdf, red);
     const long long s0 = span[0], s1 = span[1];         // global offspring span of this source tile
     auto to_local = [&](long long g) -> int { g -= gOff; return g < 0 ? 0 : (g > n ? n : (int)g); };
     const int i0 = to_local(s0), i1 = to_local(s1);     // the part of it that lands in this shard's own arrays
@@ -669,7 +651,7 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
             const long long f1 = seg == 0 ? (s1 < gOff ? s1 : gOff) : s1;
             for (long long i = f0 + tid; i < f1; i += kThreads) {
                 const double u = rStart + rStep * (double)i;
-                const int j = upper_bound_tile(cdf, nValid, u);
+                const int j = tile_ancestor(cdf, small, nValid, tileStart, u);
                 float x, y, z, th;
                 if (i < numSpawn) {
                     spawn_from_range(keyRs, (uint64_t)i, sbx, sby, sbz, srange, sstd, x, y, z, th);
@@ -726,7 +708,7 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const double u = rStart + rStep * (SHARDED ? dOff + (double)(e + m) : (double)(e + m));     // pfResample.c:71
-                jj[m] = upper_bound_tile(cdf, nValid, u);
+                jj[m] = tile_ancestor(cdf, small, nValid, tileStart, u);
             }
             float ow[4], ox[4], oy[4], oz[4], ot[4];
 #pragma unroll
@@ -754,7 +736,7 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
                 const float pRange = sqrtf(gx * gx + gy * gy + gz * gz);
                 if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
                 ow[m] = wi;
-                acc[0] += wi;
+                acc[0] += cdf_weight(wi);
                 acc[1] += wi * wi;
                 acc[2] += wi * cs;
                 acc[3] += wi * sn;
@@ -877,7 +859,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_land(LocBufs bufs, const LocCt
             const float gx = x - ga.bx, gy = y - ga.by, gz = z - ga.bz;
             const float pRange = sqrtf(gx * gx + gy * gy + gz * gz);
             if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
-            acc[0] += wi;
+            acc[0] += cdf_weight(wi);
             acc[1] += wi * wi;
             acc[2] += wi * cs;
             acc[3] += wi * sn;
@@ -917,7 +899,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_pose_tiles(LocBufs bufs, const
         float sn, cs;
         sincos_bounded(th[k], sn, cs);
         acc[0] += wi * x[k]; acc[1] += wi * y[k]; acc[2] += wi * z[k];
-        acc[3] += wi * cs; acc[4] += wi * sn; acc[5] += wi;
+        acc[3] += wi * cs; acc[4] += wi * sn; acc[5] += cdf_weight(wi);
     }
     block_sum_store<6>(acc, red, rsPart + (size_t)blockIdx.x * kRsPerTile);
 }

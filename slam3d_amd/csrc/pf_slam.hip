@@ -15,6 +15,7 @@
 #include <ctime>
 #include <mutex>
 #include <new>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -109,6 +110,9 @@ struct pfx_slam {
     void* hScratch = nullptr;       // pinned: pose sums, branch flags
     std::vector<FilterHost> fl;
     long long deposits = 0;
+    // reference-layout API: slot of every bcn_t this filter has met, by struct address.  particleFilterSlam_addBcn
+    // (the reference's way of resetting a beacon) wipes the struct's own binding record; the address finds the slot again.
+    std::unordered_map<uintptr_t, int> legacySlots;
 };
 
 static std::mutex g_smu;
@@ -403,6 +407,7 @@ extern "C" int pfx_slam_reset(pfx_slam* pf, int f, uint32_t seed)
     DeviceGuard g(pf->device);
     pf->fl[f] = FilterHost();
     pf->fl[f].seed = seed;
+    if (f == 0) pf->legacySlots.clear();
     hipLaunchKernelGGL(k_slam_tag_init, dim3((unsigned)((pf->D.tagStride + 255) / 256)), dim3(256), 0, pf->stream, pf->P, pf->D, f, 1);
     return check_launch("k_slam_tag_init");
 }
@@ -655,7 +660,7 @@ pfx_slam* bound(const particleFilterSlam_t* pf)
 pfx_slam* must_be_bound(const particleFilterSlam_t* pf, const char* fn)
 {
     pfx_slam* h = bound(pf);
-    if (!h) { set_error("%s: struct %p was not initialised with particleFilterSlam_init (or was moved)", fn, (const void*)pf); die(fn); }
+    if (!h) { set_error("%s: struct %p was not initialised with particleFilterSlam_init (or was moved)", fn, (const void*)pf); fail(fn); }
     return h;
 }
 
@@ -685,15 +690,46 @@ int legacy_device()
     return (e && *e) ? atoi(e) : 0;
 }
 
-// slot of a beacon struct inside the filter's device state; bound at its first use with that filter
+// AoS particles of a caller's struct -> the SoA arrays pfx_slam_upload_* take
+template <typename P>
+void aos_to_soa(const P* p, size_t n, std::vector<float>& out)
+{
+    out.resize(n * 5);
+    for (size_t i = 0; i < n; ++i) {
+        out[i] = p[i].w; out[n + i] = p[i].x; out[2 * n + i] = p[i].y; out[3 * n + i] = p[i].z; out[4 * n + i] = p[i].theta;
+    }
+}
+
+// Slot of a beacon struct inside the filter's device state; bound at its first use with that filter.  The reference
+// has no limit on the beacons of a filter; here a filter holds at most kSlamMaxBcns (32) distinct bcn_t at a time.
 int slot_of(pfx_slam* h, bcn_t* b, const char* fn)
 {
     BcnStash* s = stash_of(b);
     if (s->magic == kBcnMagic && s->self == (uint64_t)(uintptr_t)b && s->owner == h && s->slot >= 0 && s->slot < h->fl[0].numBcns)
         return (int)s->slot;
-    const int slot = pfx_slam_add_bcn(h, 0);
-    if (slot < 0) die(fn);
+    int slot;
+    const auto it = h->legacySlots.find((uintptr_t)b);
+    if (it != h->legacySlots.end()) {
+        slot = it->second;                  // reset with particleFilterSlam_addBcn: same struct, same slot, spawned afresh
+    } else {
+        slot = pfx_slam_add_bcn(h, 0);
+        if (slot < 0) return -1;
+        h->legacySlots[(uintptr_t)b] = slot;
+    }
     h->fl[0].bcnInit[slot] = false;
+    if (b->initialized) {
+        // A beacon that says it holds particles but has no rows on the device (a struct filled by the reference
+        // library, or a copy of one taken after pfx_slam_sync_host): its own arrays are the state, as in the reference.
+        if (h->D.nTag != PF_N_TAG_SLAM || h->D.nBcn != PF_N_BCN) {
+            set_error("%s: beacon %p is initialised but not on the device, and the particle counts were overridden", fn, (const void*)b);
+            return -1;
+        }
+        const size_t n = (size_t)PF_N_TAG_SLAM * PF_N_BCN;
+        std::vector<float> tmp;
+        aos_to_soa(&b->pBcn[0][0], n, tmp);
+        // binding record first: pBcnBuf, where it lives, is not part of the state
+        if (pfx_slam_upload_bcn(h, 0, slot, &tmp[0], &tmp[n], &tmp[2 * n], &tmp[3 * n], &tmp[4 * n], 1)) return -1;
+    }
     s->magic = kBcnMagic; s->self = (uint64_t)(uintptr_t)b; s->owner = h; s->slot = slot;
     return slot;
 }
@@ -701,7 +737,19 @@ int slot_of(pfx_slam* h, bcn_t* b, const char* fn)
 void legacy_deposit(particleFilterSlam_t* pf, bcn_t* bcn, float range, float stdRange, bcn_t** allBcns, int numBcns, const char* fn)
 {   // particleFilter.c:193-211
     pfx_slam* h = must_be_bound(pf, fn);
+    if (!h) return;
     DeviceGuard g(h->device);
+    // every beacon gets its slot before anything is committed, so that a failure leaves the call without effect
+    int slots[kSlamMaxBcns];
+    if (numBcns > kSlamMaxBcns) {
+        set_error("%s: %d beacons in allBcns, this library holds at most %d per filter", fn, numBcns, kSlamMaxBcns);
+        fail(fn);
+        return;
+    }
+    for (int i = 0; i < numBcns; ++i)
+        if ((slots[i] = slot_of(h, allBcns[i], fn)) < 0) { fail(fn); return; }
+    const int target = slot_of(h, bcn, fn);
+    if (target < 0) { fail(fn); return; }
     StepReq r{};
     r.f = 0; r.range = range; r.stdRange = stdRange;
     VioAcc v = vio_load(pf);
@@ -709,31 +757,42 @@ void legacy_deposit(particleFilterSlam_t* pf, bcn_t* bcn, float range, float std
     vio_store(pf, v);
     r.activeMask = 0;
     for (int i = 0; i < numBcns; ++i) {
-        const int c = slot_of(h, allBcns[i], fn);
+        const int c = slots[i];
         VioAcc bv = vio_load(allBcns[i]);
         vio_commit(bv, r.bcnDelta[c]);
         vio_store(allBcns[i], bv);
         r.activeMask |= 1u << c;
         h->fl[0].bcnInit[c] = allBcns[i]->initialized != 0;    // the struct's flag is authoritative
     }
-    r.target = slot_of(h, bcn, fn);
+    r.target = target;
     h->fl[0].bcnInit[r.target] = bcn->initialized != 0;
-    if (slam_step(h, &r, 1)) die(fn);
+    if (slam_step(h, &r, 1)) { fail(fn); return; }
     bcn->initialized = 1;
 }
 
 }  // namespace
 
 extern "C" void particleFilterSlam_init(particleFilterSlam_t* pf)
-{   // particleFilter.c:48-63 + pfRandom.c:56-60 (seed from the clock unless one was set)
+{   // particleFilter.c:48-63 + pfRandom.c:56-60 (seed from the clock unless one was set).  Filters initialised after one
+    // particleFilterSeed_set share Philox key word 1 = 0 for their tag particles and slot + 1 for their beacons, so the
+    // n-th of them gets its own key word 0: the seed plus n golden-ratio steps (n = 0: the seed itself).
     if (!PF_SEED_SET) PF_SEED = (unsigned int)time(nullptr);
+    const uint32_t seed = PF_SEED + 0x9E3779B9u * next_filter_stream();
     pfx_slam* h = bound(pf);
     if (h) {
-        if (pfx_slam_reset(h, 0, PF_SEED)) die("particleFilterSlam_init");
+        // The reference resets the tag particles and the VIO scalars and nothing else: the beacons are structs of
+        // their own and keep their particles (and here their slots).
+        DeviceGuard g(h->device);
+        FilterHost& fh = h->fl[0];
+        fh.vio = VioAcc();
+        fh.seed = seed;
+        fh.epoch = 0;
+        hipLaunchKernelGGL(k_slam_tag_init, dim3((unsigned)((h->D.tagStride + 255) / 256)), dim3(256), 0, h->stream, h->P, h->D, 0, 1);
+        if (check_launch("k_slam_tag_init")) { fail("particleFilterSlam_init"); return; }
     } else {
         h = pfx_slam_create(1, legacy_n("PF_HIP_N_TAG_SLAM", PF_N_TAG_SLAM), legacy_n("PF_HIP_N_BCN", PF_N_BCN), kSlamMaxBcns, nullptr,
-                            PF_SEED, legacy_device());
-        if (!h) die("particleFilterSlam_init");
+                            seed, legacy_device());
+        if (!h) { fail("particleFilterSlam_init"); return; }
         SlamStash* s = stash_of(pf);
         s->magic = kSlamMagic; s->self = (uint64_t)(uintptr_t)pf; s->handle = h;
     }
@@ -778,8 +837,9 @@ extern "C" uint8_t particleFilterSlam_getTagLoc(const particleFilterSlam_t* pf, 
 {
     if (!pf->initialized) return 0;
     pfx_slam* h = must_be_bound(pf, "particleFilterSlam_getTagLoc");
+    if (!h) return 0;
     DeviceGuard g(h->device);
-    if (tag_pose_sums(h)) die("particleFilterSlam_getTagLoc");
+    if (tag_pose_sums(h)) { fail("particleFilterSlam_getTagLoc"); return 0; }
     tag_pose_finish((const double*)h->hScratch, vio_load(pf), t, x, y, z, theta);
     return 1;
 }
@@ -789,14 +849,16 @@ extern "C" uint8_t particleFilterSlam_getBcnLoc(const particleFilterSlam_t* pf, 
 {
     if (!bcn->initialized) return 0;
     pfx_slam* h = must_be_bound(pf, "particleFilterSlam_getBcnLoc");
+    if (!h) return 0;
     const BcnStash* s = stash_of(bcn);
     if (s->magic != kBcnMagic || s->self != (uint64_t)(uintptr_t)bcn || s->owner != h) {
         set_error("particleFilterSlam_getBcnLoc: beacon %p has never been deposited to this filter", (const void*)bcn);
-        die("particleFilterSlam_getBcnLoc");
+        fail("particleFilterSlam_getBcnLoc");
+        return 0;
     }
     DeviceGuard g(h->device);
     const int slot = (int)s->slot;
-    if (bcn_pose_sums(h, &slot)) die("particleFilterSlam_getBcnLoc");
+    if (bcn_pose_sums(h, &slot)) { fail("particleFilterSlam_getBcnLoc"); return 0; }
     bcn_pose_finish((const double*)h->hScratch, pf->lastT, t, x, y, z, theta);
     return 1;
 }

@@ -145,7 +145,7 @@ __device__ __forceinline__ SmallDecision small_filter_update(Row4& r, const floa
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float wi = (j0 + k < n) ? r.w[k] : 0.0f;
-        run += wi;
+        run += cdf_weight(wi);          // exact sums (pf_common.h, CDF rule)
         a[k] = run;
         acc[1] += wi * wi;
         acc[2] += wi * cs[k];
@@ -231,7 +231,7 @@ __device__ __forceinline__ SmallDecision small_filter_update_lazy_theta(Row4& r,
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float wi = (j0 + k < n) ? r.w[k] : 0.0f;
-        acc[0] += wi;
+        acc[0] += cdf_weight(wi);       // exact sums (pf_common.h, CDF rule)
         acc[1] += wi * wi;
     }
     double* const park = L.cdf;         // 2 * kThreads doubles here
@@ -276,7 +276,7 @@ __device__ __forceinline__ SmallDecision small_filter_update_lazy_theta(Row4& r,
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float wi = (j0 + k < n) ? r.w[k] : 0.0f;
-        run += wi;
+        run += cdf_weight(wi);
         a[k] = run;
         r.th[k] = wrap_two_pi(r.th[k]);
         float sn, cs;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(kThreads) void k_slam_tag_pose(SlamPtrs P, SlamDims
         float sn, cs;
         sincos_bounded(r.th[k], sn, cs);
         const float w = r.w[k];
-        acc[0] += w; acc[1] += w * r.x[k]; acc[2] += w * r.y[k]; acc[3] += w * r.z[k]; acc[4] += w * cs; acc[5] += w * sn;
+        acc[0] += cdf_weight(w); acc[1] += w * r.x[k]; acc[2] += w * r.y[k]; acc[3] += w * r.z[k]; acc[4] += w * cs; acc[5] += w * sn;
     }
     block_sum_store<6>(acc, red, tagPose + (size_t)f * 6);
 }
@@ -632,14 +632,14 @@ __global__ __launch_bounds__(kThreads) void k_slam_bcn_rows_pose(SlamPtrs P, Sla
         float sn, cs;
         sincos_bounded(r.th[k], sn, cs);
         const float w = r.w[k] * scale;
-        acc[0] += w; acc[1] += w * r.x[k]; acc[2] += w * r.y[k]; acc[3] += w * r.z[k]; acc[4] += w * cs; acc[5] += w * sn;
+        acc[0] += cdf_weight(w); acc[1] += w * r.x[k]; acc[2] += w * r.y[k]; acc[3] += w * r.z[k]; acc[4] += w * cs; acc[5] += w * sn;
     }
     block_sum<6>(acc, red);
     if (threadIdx.x == 0) {
         const float w1 = P.tag[0][(size_t)f * D.tagStride + i];
         const float s2 = (float)acc[0];
         float* o = rowTerms + ((size_t)f * D.nTag + i) * 6;
-        o[0] = w1;
+        o[0] = cdf_weight(w1);
 #pragma unroll
         for (int k = 1; k < 6; ++k) o[k] = w1 * (float)acc[k] / s2;
     }

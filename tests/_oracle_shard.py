@@ -15,6 +15,11 @@ from oracle import oracle as ora
 f32 = np.float32
 
 
+def cdf_weight(w):
+    """oracle/pf_oracle.c ora_cdf_weight on a float32 array: nearest multiple of 2^-20 (ties to even), as float64"""
+    return (np.rint(w.astype(np.float32) * f32(1048576.0)) * f32(9.5367431640625e-07)).astype(np.float64)
+
+
 def _p(a, t=C.c_float):
     return a.ctypes.data_as(C.POINTER(t))
 
@@ -107,7 +112,7 @@ class OracleShard:
         self.wscale = f32(1.0)
         self.pf.apply_vio(*self._vio)
         self.pf.apply_range(bx, by, bz, rng, std)
-        w64 = w.astype(np.float64)
+        w64 = cdf_weight(w)
         c, s = np.cos(th).astype(np.float32), np.sin(th).astype(np.float32)
         sums = [w64.sum(), (w * w).astype(np.float64).sum(), (w * c).astype(np.float64).sum(),
                 (w * s).astype(np.float64).sum(), (w * x).astype(np.float64).sum(), (w * y).astype(np.float64).sum(),
@@ -157,7 +162,7 @@ class OracleShard:
         """own-range offspring into the arrays (weight 1), foreign ones staged as records"""
         epoch, (bx, by, bz, rng, std) = self._rs
         w, x, y, z, th = self.pf.arrays()
-        cdf = self.base[self.rank] + np.cumsum(w.astype(np.float64))
+        cdf = self.base[self.rank] + np.cumsum(cdf_weight(w))
         ob, oe = self.F[self.rank], self.F[self.rank + 1]
         cnt = oe - ob
         i = np.arange(ob, oe, dtype=np.float64)
@@ -208,7 +213,7 @@ class OracleShard:
             self.stream()
         else:
             w, x, y, z, th = arrs
-            self.pose_local = np.array([w.astype(np.float64).sum(), x.astype(np.float64).sum(), y.astype(np.float64).sum(),
+            self.pose_local = np.array([cdf_weight(w).sum(), x.astype(np.float64).sum(), y.astype(np.float64).sum(),
                                         z.astype(np.float64).sum(), np.cos(th).astype(np.float64).sum(),
                                         np.sin(th).astype(np.float64).sum()])
 
