@@ -223,12 +223,13 @@ def test_systematic_resampling_properties_large(pfm):
     g.resample(0.0, 0.0, 0.0, 10.0, 0.1)
     st = g.last_stats()
     assert int(st["branch"]) == 1 and int(st["numSpawn"]) == 0
-    assert st["S"] == pytest.approx(float(w.astype(np.float64).sum()), rel=1e-13)
+    wq = (np.rint(w * np.float32(1048576.0)) * np.float32(9.5367431640625e-07)).astype(np.float64)   # cdf_weight
+    assert st["S"] == float(wq.sum())                   # exact: multiples of 2^-20, any order
     anc = g.last_ancestors()
     assert anc.min() >= 0 and anc.max() < n and np.all(np.diff(anc) >= 0)
     counts = np.bincount(anc, minlength=n)
     assert counts.sum() == n
-    expect = w.astype(np.float64) / st["rStep"]
+    expect = wq / st["rStep"]
     assert np.all(counts >= np.floor(expect) - 1e-9) and np.all(counts <= np.ceil(expect) + 1e-9)
     gw = g.download()[0]
     assert np.all(gw == 1.0)
@@ -289,34 +290,66 @@ def _scene_events(n_steps):
     return ev
 
 
-@pytest.mark.parametrize("n", [10000, 50021])
-def test_deposit_sequence_tracks_oracle(pfm, ora, n):
-    """Config-3 style scene (8 beacons, circle walk): every deposit on the GPU vs the oracle with the same
-    Philox key.  Same branch decisions; per-particle state within float tolerance while no gate decision
-    flips (a particle within ~1e-6 m of the 3-sigma shell can gate differently: its weight then differs
-    by the factor minWeight, which the test allows for a handful of particles); poses within 1e-4."""
-    g, o = _pair(pfm, ora, n)
-    ev = _scene_events(24)
-    k = 0
-    for e in ev:
+def _track_oracle(g, o, events, n, pose_every=1):
+    """Drive the GPU filter and the oracle (same Philox key) through `events` and compare after every deposit.
+
+    While the two runs are PARTICLE-EXACT the weight total S (an exact sum on both sides) is equal bit for bit, the
+    decisions are equal and the poses agree to 1e-4.  They stop being particle-exact only through the range gate:
+    positions agree to ~2e-6 m (device sin/cos/log vs glibc), so a particle that close to the 3-sigma shell can be
+    gated on one side only (about N * 5e-6 of them per deposit).  That shows as S differing by a few (1 - minWeight)
+    steps; it is checked to be exactly that -- all weights in one common ratio (the normalisation factor) except a
+    handful -- and from there on the runs are two samples of the same posterior: the next resampling puts different
+    u_i under every CDF step, so the bars become statistical (pose within 0.02 m / rad of each other, well above the
+    sampling noise spread / sqrt(N) at N >= 10 000).  Returns (deposits, first deposit that was not exact or None)."""
+    k, diverged_at = 0, None
+    for e in events:
         for f in (g, o):
-            _drive(f, [e])
+            _deposit_only(f, [e])
         if e[0] == "vio":
             continue
         k += 1
-        gs = g.last_stats() if k > 1 else None
-        if gs is not None:
-            os_ = o.last_stats()
-            assert int(gs["branch"]) == int(os_["branch"]), f"deposit {k}"
-            assert int(gs["numSpawn"]) == int(os_["numSpawn"])
-        a, b = g.getTagLoc(), o.getTagLoc()
-        assert np.abs(np.array(a[2:], dtype=np.float64) - np.array(b[2:], dtype=np.float64)).max() <= 1e-4, f"deposit {k}"
+        if k == 1:
+            continue                                    # the first range spawns
+        gs, os_ = g.last_stats(), o.last_stats()
+        assert int(gs["branch"]) == int(os_["branch"]), f"deposit {k}"
+        assert int(gs["numSpawn"]) == int(os_["numSpawn"]), f"deposit {k}"
+        if diverged_at is None and gs["S"] != os_["S"]:
+            diverged_at = k
+            gw, ow = g.download()[0].astype(np.float64), o.arrays()[0].astype(np.float64)
+            ratio = gw / ow
+            odd = np.abs(ratio / np.median(ratio) - 1.0) > 1e-5
+            assert 0 < odd.sum() <= max(3, n // 2000), f"deposit {k}: {int(odd.sum())} weights differ beyond a common factor"
+            assert abs(gs["S"] - os_["S"]) <= 0.9 * odd.sum() * max(1.0, float(ow.max())), f"deposit {k}"
+        if diverged_at is None:
+            assert gs["s"] == os_["s"] and gs["m"] == os_["m"], f"deposit {k}"
+            if int(gs["branch"]):
+                assert gs["rStart"] == os_["rStart"] and gs["rStep"] == os_["rStep"], f"deposit {k}"
+        else:
+            assert gs["ess"] == pytest.approx(os_["ess"], rel=0.02), f"deposit {k}"
+        if k % pose_every == 0:
+            a, b = g.getTagLoc(), o.getTagLoc()
+            d = np.abs(np.array(a[2:], dtype=np.float64) - np.array(b[2:], dtype=np.float64))
+            d[3] = min(d[3], abs(d[3] - 2 * np.pi))
+            assert d.max() <= (1e-4 if diverged_at is None else 0.02), f"deposit {k}: {a} vs {b}"
     got, exp = g.download(), o.arrays()
-    wdiff = np.abs(got[0] - exp[0]) > 1e-5 * np.maximum(1.0, np.abs(exp[0]))
-    assert wdiff.sum() <= max(3, n // 5000)
-    for c in range(1, 4):
-        d = np.abs(got[c] - exp[c])
-        assert np.quantile(d, 0.999) <= 1e-4
+    if diverged_at is None:
+        assert np.array_equal(got[0], exp[0])
+        for c in range(1, 4):
+            assert np.abs(got[c] - exp[c]).max() <= 1e-5
+    else:
+        q = np.linspace(0.05, 0.95, 19)
+        for c in range(1, 4):
+            assert np.abs(np.quantile(got[c], q) - np.quantile(exp[c], q)).max() < 0.05
+    return k, diverged_at
+
+
+@pytest.mark.parametrize("n", [10000, 50021])
+def test_deposit_sequence_tracks_oracle(pfm, ora, n):
+    """Config-3 style scene (8 beacons, circle walk): every deposit on the GPU vs the oracle with the same
+    Philox key, a pose query after each (so every resampling runs as its own kernel).  See _track_oracle."""
+    g, o = _pair(pfm, ora, n)
+    k, _ = _track_oracle(g, o, _scene_events(24), n)
+    assert k == 32
 
 
 # ------------------------------------------------------------------ deferred resampling (k_loc_resample_deposit)
@@ -395,26 +428,67 @@ def test_deferred_sequence_tracks_oracle(pfm, ora, n):
     """The oracle comparison of test_deposit_sequence_tracks_oracle with the GPU pose read only every fifth
     deposit, so that most deposits run through the deferred path (last_stats reads the control block only)."""
     g, o = _pair(pfm, ora, n)
-    k = 0
-    for e in _scene_events(30):
+    k, _ = _track_oracle(g, o, _scene_events(30), n, pose_every=5)
+    assert k == 40
+
+
+def test_sequence_exact_until_first_gate_flip(pfm, ora):
+    """At N = 10 000 a gate flip is rare enough (about one deposit in twenty) that this scene stays particle-exact
+    through several resampling steps: the weight total S of every one of the first 30 deposits equals the oracle's bit
+    for bit, and the ancestors of every resampling among them are identical (deferred path off: ancestors recorded)."""
+    n = 10000
+    g, o = _pair(pfm, ora, n)
+    g.record_ancestors(True)
+    k = resamplings = 0
+    for e in _scene_events(24):
         for f in (g, o):
             _deposit_only(f, [e])
         if e[0] == "vio":
             continue
         k += 1
-        if k > 1:
-            gs, os_ = g.last_stats(), o.last_stats()
-            assert int(gs["branch"]) == int(os_["branch"]), f"deposit {k}"
-            assert int(gs["numSpawn"]) == int(os_["numSpawn"])
-            assert abs(gs["ess"] - os_["ess"]) <= 1e-3 * os_["ess"] + (n // 5000) * 1.0, f"deposit {k}"
-        if k % 5 == 0:
-            a, b = g.getTagLoc(), o.getTagLoc()
-            assert np.abs(np.array(a[2:], dtype=np.float64) - np.array(b[2:], dtype=np.float64)).max() <= 1e-4, f"deposit {k}"
+        if k == 1:
+            continue
+        gs, os_ = g.last_stats(), o.last_stats()
+        if gs["S"] != os_["S"]:
+            break
+        assert int(gs["branch"]) == int(os_["branch"])
+        if int(gs["branch"]):
+            assert np.array_equal(g.last_ancestors(), o.last_ancestors()), f"deposit {k}"
+            resamplings += 1
+    assert k >= 30 and resamplings >= 5, (k, resamplings)
+
+
+@pytest.mark.parametrize("n", [1 << 24, 1 << 26])
+def test_resample_stage_beyond_2p24(pfm, ora, n):
+    """N = 2^24 and 64 M (the single-GPU denominator of BASELINE config 4), where the reference's float32 running sum is
+    void (pfResample.c:45-49: adding 1.0f to 2^24 is a no-op).  Identical weights on both sides: the exact total, the
+    decision scalars, rStart / rStep and EVERY ancestor index of the resampling equal the oracle's serial float64 loop."""
+    g, o = _pair(pfm, ora, n, seed=99)
+    u = _synth.u01(1234, n)
+    w = np.where(u < 0.1, 1.0, np.where(u < 0.2, 0.3, 0.1)).astype(np.float32)     # ESS / N ~ 0.37: resamples
+    z = np.zeros(n, dtype=np.float32)
+    th = (u * np.float32(6.0)).astype(np.float32)
+    for f in (g, o):
+        if f is g:
+            f.upload(w, z, z, z, th, initialized=True)
+        else:
+            f.set_particles(w, z, z, z, th)
+            f.set_initialized(1)
+        f.epoch = 21
+    g.record_ancestors(True)
+    g.resample(1.0, 2.0, 0.5, 6.0, 0.1)
+    o.resample(1.0, 2.0, 0.5, 6.0, 0.1)
+    gs, os_ = g.last_stats(), o.last_stats()
+    assert int(gs["branch"]) == int(os_["branch"]) == 1 and int(gs["numSpawn"]) == int(os_["numSpawn"]) == 0
+    assert gs["S"] == os_["S"] and gs["s"] == os_["s"]
+    assert gs["rStart"] == os_["rStart"] and gs["rStep"] == os_["rStep"]
+    assert gs["ss"] == pytest.approx(os_["ss"], rel=1e-12) and gs["ess"] == pytest.approx(os_["ess"], rel=1e-6)
+    anc_g, anc_o = g.last_ancestors(), o.last_ancestors()
+    assert np.array_equal(anc_g, anc_o)
     got, exp = g.download(), o.arrays()
-    wdiff = np.abs(got[0] - exp[0]) > 1e-5 * np.maximum(1.0, np.abs(exp[0]))
-    assert wdiff.sum() <= max(3, n // 5000)
+    assert np.all(got[0] == 1.0)
     for c in range(1, 4):
-        assert np.quantile(np.abs(got[c] - exp[c]), 0.999) <= 1e-4
+        assert np.abs(got[c][::7] - exp[c][::7]).max() <= 5e-6
 
 
 def test_rssi_is_fixed_range(pfm):
