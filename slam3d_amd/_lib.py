@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libparticlefilter.so")
+# PFX_LIB_PATH: another build of the same library (kernel experiments, tools/dev); the product path is the default
+LIB_PATH = os.environ.get("PFX_LIB_PATH") or os.path.join(_HERE, "lib", "libparticlefilter.so")
 
 _lib = None
 

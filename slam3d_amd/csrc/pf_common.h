@@ -78,6 +78,9 @@ struct RngKey { uint32_t seed, stream, epoch; };
 
 __host__ __device__ __forceinline__ u32x4 rng_block(const RngKey& k, uint32_t purpose, uint64_t index, uint32_t block)
 {
+#ifdef PF_EXPERIMENT_NO_PHILOX      // tools/dev timing experiments only: what the kernels cost without the generator
+    return { (uint32_t)index * 2654435761u, k.epoch + purpose, (uint32_t)index + block, k.seed };
+#endif
     return philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), k.epoch, purpose + 16u * block, k.seed, k.stream);
 }
 
@@ -139,10 +142,28 @@ __device__ __forceinline__ float log_unit(float u)
 // absolute in the unit normal, i.e. 4e-8 m after the 0.1 m jitter scale, 4e-10 m after the VIO noise scale.
 __device__ __forceinline__ void normal2(uint32_t w0, uint32_t w1, float& a, float& b)
 {
+#ifdef PF_EXPERIMENT_NO_BOXMULLER   // tools/dev timing experiments only
+    a = uniform_nonzero(w0) - 0.5f; b = uniform_nonzero(w1) - 0.5f; return;
+#endif
     const float f = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(uniform_nonzero(w0)) * -1.38629436111989061883f);   // -2 ln 2
     const float u2 = uniform_nonzero(w1);
     a = f * __builtin_amdgcn_cosf(u2);
     b = f * __builtin_amdgcn_sinf(u2);
+}
+
+// sqrtf(x), correctly rounded, for x = 0 or x in the normal range (squared distances in metres): the hardware square
+// root (1 ulp) corrected by the two residual tests the compiler's own expansion uses, without that expansion's
+// rescaling of denormal arguments and its class test -- nine instructions instead of seventeen.  Bit-identical to
+// sqrtf for every argument that is not denormal, infinite or NaN.
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x);     // x - s_minus * s
+    const float rp = __builtin_fmaf(-sp, s, x);     // x - s_plus * s
+    float r = (rm <= 0.0f) ? sm : s;
+    r = (rp > 0.0f) ? sp : r;
+    return r;
 }
 
 // fmodf(x, 2*pi_f) with the result keeping x's sign (pfMeasurement.c:47, pfInit.c:78).  For
@@ -228,6 +249,9 @@ __device__ __forceinline__ void motion_particle(const RngKey& key, uint64_t inde
         c0 = __builtin_fmaf(d, sn, __builtin_fmaf(-h, cs, cs));     // cos(theta - d)
         s0 = __builtin_fmaf(-d, cs, __builtin_fmaf(-h, sn, sn));    // sin(theta - d)
     } else {
+        // (the empty volatile statement keeps this a branch: without it the compiler evaluates this side's extra sincos
+        // for every particle and selects afterwards -- 25 instructions per particle in kernels bound by vector-ALU issue)
+        asm volatile("; heading noise too large for the angle-difference form");
         sincos_bounded(th, s0, c0);
         th = wrap_two_pi(th + d);
         sincos_bounded(th, sn, cs);

@@ -115,6 +115,7 @@ struct pfx_loc {
     float deferArg[5] = { 0, 0, 0, 0, 0 };
     double* pieceSums = nullptr;    // 2 * numTiles * kSumsPerTile: per (source tile, destination tile) sums
     int* pieceSlots = nullptr;      // head slot [numTiles], tail slot [numTiles]
+    int* srcTileOf = nullptr;       // numTiles: source tile of the first offspring of every destination tile (k_loc_decide_map)
     LocCtl* ctl = nullptr;
     LocCtl* hostCtl = nullptr;      // pinned
     uint32_t seed = 0, streamId = 0, epoch = 0;
@@ -230,6 +231,11 @@ int launch_decide(pfx_loc* pf, float range, bool localOnly = false, bool pieces 
     if (localOnly)
         hipExtLaunchKernelGGL((k_loc_decide<true>), dim3(1), dim3(kDecideThreads), 0, pf->stream, nullptr, ps.b(), 0, pf->ctl,
                               pf->chunkSums, pf->chunkBase, pf->numChunks, pf->n, range, key_of(pf), pf->force, pf->branchLog);
+    else if (pf->numShards == 1 && !pf->stageSlab)
+        // unsharded: decision + source map of the destination-owned resampling
+        hipExtLaunchKernelGGL(k_loc_decide_map, dim3(pf->numChunks), dim3(kThreads), 0, pf->stream, nullptr, ps.b(), 0, pf->ctl,
+                              pf->chunkSums, pf->chunkBase, pf->tileIncl, pf->srcTileOf, pf->numChunks, pf->numTiles, pf->n, range,
+                              key_of(pf), pf->force, pf->branchLog);
     else
         hipExtLaunchKernelGGL((k_loc_decide<false>), dim3(1), dim3(kDecideThreads), 0, pf->stream, nullptr, ps.b(), 0, pf->ctl,
                               pf->chunkSums, pf->chunkBase, pf->numChunks, pf->n, range, key_of(pf), pf->force, pf->branchLog);
@@ -240,15 +246,26 @@ int launch_resample(pfx_loc* pf, const RngKey& key, float bx, float by, float bz
 {
     ProfScope ps(pf, PFX_K_RESAMPLE);
     const dim3 grid(pf->numTiles), block(kThreads);
+    if (pf->numShards == 1 && !pf->stageSlab) {
+        // unsharded: workgroup d produces destination tile d (k_loc_resample_dest)
+        const RespawnShell sh{ bx, by, bz, range, stdRange };
+#define PF_LAUNCH_RSD(R, P) \
+    hipExtLaunchKernelGGL((k_loc_resample_dest<R, P>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase, \
+                          pf->tileIncl, pf->recordAnc ? pf->anc : (int*)nullptr, pf->numTiles, (int)pf->n, key, sh, pf->rsPart, \
+                          pf->srcTileOf)
+        if (pf->recordAnc) PF_LAUNCH_RSD(true, false);
+        else if (pose) PF_LAUNCH_RSD(false, true);
+        else PF_LAUNCH_RSD(false, false);
+#undef PF_LAUNCH_RSD
+        return check_launch("k_loc_resample_dest");
+    }
+    // one shard of a sharded filter: a workgroup produces the offspring of its own source tile (k_loc_resample)
     StagePtrs st{};
     st.rec = reinterpret_cast<float4*>(pf->stageSlab);
     st.cap = pf->stageSlab ? (long long)pf->stageCap : 0;
     if (pf->recordAnc)
         hipExtLaunchKernelGGL((k_loc_resample<true, false>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase,
                            pf->tileIncl, pf->anc, pf->numTiles, pf->n, st, key, bx, by, bz, range, stdRange, pf->rsPart);
-    else if (pose && pf->numShards == 1 && !pf->stageSlab)
-        hipExtLaunchKernelGGL((k_loc_resample<false, true>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase,
-                           pf->tileIncl, (int*)nullptr, pf->numTiles, pf->n, st, key, bx, by, bz, range, stdRange, pf->rsPart);
     else
         hipExtLaunchKernelGGL((k_loc_resample<false, false>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase,
                            pf->tileIncl, (int*)nullptr, pf->numTiles, pf->n, st, key, bx, by, bz, range, stdRange, pf->rsPart);
@@ -263,10 +280,9 @@ int launch_deposit(pfx_loc* pf, bool motion, const Motion& mo, const Gate& ga)
     const dim3 grid(pf->numTiles), block(kThreads);
     const float* a = pf->deferArg;
     const RespawnShell sh{ a[0], a[1], a[2], a[3], a[4] };
-    const PieceOut out{ pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles };
 #define PF_LAUNCH_DEP(M) \
     hipExtLaunchKernelGGL((k_loc_deposit<M>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->tileSums, \
-                          pf->chunkBase, pf->tileIncl, pf->numTiles, (int)pf->n, pf->deferKey, sh, key_of(pf), mo, ga, out)
+                          pf->chunkBase, pf->tileIncl, pf->numTiles, (int)pf->n, pf->deferKey, sh, key_of(pf), mo, ga, pf->srcTileOf)
     if (motion) PF_LAUNCH_DEP(true);
     else PF_LAUNCH_DEP(false);
 #undef PF_LAUNCH_DEP
@@ -336,6 +352,7 @@ void free_device(pfx_loc* pf)
     if (pf->anc) hipFree(pf->anc);
     if (pf->pieceSums) hipFree(pf->pieceSums);
     if (pf->pieceSlots) hipFree(pf->pieceSlots);
+    if (pf->srcTileOf) hipFree(pf->srcTileOf);
     if (pf->branchLog) hipFree(pf->branchLog);
     if (pf->ctl) hipFree(pf->ctl);
     if (pf->hostCtl) hipHostFree(pf->hostCtl);
@@ -370,6 +387,8 @@ int alloc_device(pfx_loc* pf)
     PF_HIP_OK(hipMalloc((void**)&pf->pieceSlots, 2 * nt * sizeof(int)));
     PF_HIP_OK(hipMemsetAsync(pf->pieceSums, 0, 2 * nt * kSumsPerTile * sizeof(double), pf->stream));
     PF_HIP_OK(hipMemsetAsync(pf->pieceSlots, 0, 2 * nt * sizeof(int), pf->stream));
+    PF_HIP_OK(hipMalloc((void**)&pf->srcTileOf, nt * sizeof(int)));
+    PF_HIP_OK(hipMemsetAsync(pf->srcTileOf, 0, nt * sizeof(int), pf->stream));
     PF_HIP_OK(hipMalloc((void**)&pf->branchLog, kBranchLogSize));
     PF_HIP_OK(hipMemsetAsync(pf->branchLog, 0, kBranchLogSize, pf->stream));
     PF_HIP_OK(hipMalloc((void**)&pf->ctl, sizeof(LocCtl)));
@@ -525,7 +544,7 @@ extern "C" int pfx_loc_deposit_range(pfx_loc* pf, float bx, float by, float bz, 
     // that and this deposit in one pass; otherwise it is the streaming pass.
     const bool open = pf->deferOpen;
     if (open ? launch_deposit(pf, motion, mo, ga) : launch_stream(pf, motion, true, mo, ga)) return -1;
-    if (launch_decide(pf, range, false, open)) return -1;
+    if (launch_decide(pf, range)) return -1;        // k_loc_deposit leaves the tile sums where the streaming pass does
     pf->deferOpen = true;
     pf->deferKey = key_of(pf);
     pf->deferArg[0] = bx; pf->deferArg[1] = by; pf->deferArg[2] = bz; pf->deferArg[3] = range; pf->deferArg[4] = stdRange;

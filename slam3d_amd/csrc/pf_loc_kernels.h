@@ -30,6 +30,9 @@
 
 namespace pf {
 
+#ifndef PF_STREAM_UNROLL
+#define PF_STREAM_UNROLL 1
+#endif
 struct LocBufs { float* a[2][5]; };     // [ping-pong][w,x,y,z,theta], each padded to a whole tile
 
 struct LocCtl {
@@ -103,7 +106,7 @@ __device__ __forceinline__ void stream_tile(const LocBufs& bufs, const LocCtl* _
     double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
     bool thetaChanged = false;
     const bool smallTurn = mo.stdTheta <= 1e-4f;
-#pragma unroll
+#pragma unroll PF_STREAM_UNROLL
     for (int k = 0; k < kPerThread; ++k) {
         const long long i = base + k;
         float wi = (i < n) ? w[k] * wscale : 0.0f;      // pad lanes never carry weight
@@ -122,7 +125,7 @@ __device__ __forceinline__ void stream_tile(const LocBufs& bufs, const LocCtl* _
         if (GATE) {
             // pfMeasurement.c:118-123
             const float dx = x[k] - ga.bx, dy = y[k] - ga.by, dz = z[k] - ga.bz;
-            const float pRange = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float pRange = sqrt_rn(dx * dx + dy * dy + dz * dz);
             if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
         }
         w[k] = wi;
@@ -226,61 +229,74 @@ __global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(double* __restrict__
 constexpr int kDecideThreads = 64;
 
 // The scalar part of pfResample.c:51-68,80 on the global totals tot[7] = {S, SS, C, SN, WX, WY, WZ} of n
-// particles: ESS / respawn test, heading bandwidth, rStart, or the deferred normalisation factor.
+// particles: ESS / respawn test, heading bandwidth, rStart, or the deferred normalisation factor.  A pure function of
+// its arguments (every workgroup of k_loc_decide_map evaluates it and gets the same answer).
 // force: -1 follow the reference's test, 0 never resample, 1 always resample (worst-case traffic runs).
-__device__ __forceinline__ bool decide_scalars(LocCtl* __restrict__ ctl, const double (&tot)[7], long long n, float range,
-                                               const RngKey& key, int force, unsigned char* __restrict__ branchLog)
+struct Decision { bool resample; int numSpawn; float s, ss, csum, ssum, ess, htheta, m; double S, rStart, rStep; };
+
+__device__ __forceinline__ Decision decide_compute(const double (&tot)[7], long long n, float range, const RngKey& key, int force)
 {
-    const double S = tot[0];
-    const int cur = ctl->cur;
+    Decision d;
+    d.S = tot[0];
     // pfResample.c:51-58 on the float-rounded totals
-    const float s = (float)S, ss = (float)tot[1];
-    float csum = (float)tot[2], ssum = (float)tot[3];
-    const float ess = s * s / ss;
+    d.s = (float)tot[0]; d.ss = (float)tot[1]; d.csum = (float)tot[2]; d.ssum = (float)tot[3];
+    d.ess = d.s * d.s / d.ss;
     const float invN = 1.0f / (float)n;
-    int numSpawn = 0;
-    if (s * invN < kWeightSpawnThresh && range < kRadiusSpawnThresh) numSpawn = (int)lroundf((float)n * kPctSpawn);
-    bool resample = (ess * invN < kResampleThresh) || numSpawn > 0;
-    if (force >= 0) resample = force != 0;
-    ctl->s = s; ctl->ss = ss; ctl->csum = csum; ctl->ssum = ssum; ctl->ess = ess; ctl->S = S;
-    ctl->numSpawn = numSpawn;
-    if (resample) {
+    d.numSpawn = 0;
+    if (d.s * invN < kWeightSpawnThresh && range < kRadiusSpawnThresh) d.numSpawn = (int)lroundf((float)n * kPctSpawn);
+    d.resample = (d.ess * invN < kResampleThresh) || d.numSpawn > 0;
+    if (force >= 0) d.resample = force != 0;
+    d.htheta = 0.0f; d.m = 0.0f; d.rStart = 0.0; d.rStep = 0.0;
+    if (d.resample) {
         // pfResample.c:60-68
-        csum /= s;
-        ssum /= s;
-        float h = csum * csum + ssum * ssum;
+        const float c = d.csum / d.s, sn = d.ssum / d.s;
+        float h = c * c + sn * sn;
         h = h > 1e-10f ? h : 1e-10f;
         h = h < 1.0f - 1e-10f ? h : 1.0f - 1e-10f;
-        h = sqrtf(-logf(h) / ess);
-        const double rStep = S / (double)n;
-        const double rStart = (double)uniform01(rng_block(key, P_RSTART, 0, 0).a) * rStep;
-        ctl->htheta = h; ctl->rStep = rStep; ctl->rStart = rStart;
+        d.htheta = sqrtf(-logf(h) / d.ess);
+        d.rStep = d.S / (double)n;
+        d.rStart = (double)uniform01(rng_block(key, P_RSTART, 0, 0).a) * d.rStep;
+    } else {
+        d.m = (float)n / d.s;       // pfResample.c:80-82, deferred: the next reader multiplies w by m
+    }
+    return d;
+}
+
+__device__ __forceinline__ void decide_commit(LocCtl* __restrict__ ctl, const Decision& d, unsigned char* __restrict__ branchLog)
+{
+    const int cur = ctl->cur;
+    ctl->s = d.s; ctl->ss = d.ss; ctl->csum = d.csum; ctl->ssum = d.ssum; ctl->ess = d.ess; ctl->S = d.S;
+    ctl->numSpawn = d.numSpawn;
+    if (d.resample) {
+        ctl->htheta = d.htheta; ctl->rStep = d.rStep; ctl->rStart = d.rStart;
         ctl->src = cur; ctl->dst = cur ^ 1; ctl->cur = cur ^ 1;
         ctl->wscale = 1.0f; ctl->m = 0.0f; ctl->branch = 1; ctl->rsValid = 0;
     } else {
-        // pfResample.c:80-82, deferred: the next reader multiplies w by m
-        const float m = (float)n / s;
-        ctl->wscale = m; ctl->m = m; ctl->branch = 0; ctl->htheta = 0.0f;
+        ctl->wscale = d.m; ctl->m = d.m; ctl->branch = 0; ctl->htheta = 0.0f;
     }
     const long long k = ctl->nDecisions;
-    branchLog[k % kBranchLogSize] = resample ? 1 : 0;
+    branchLog[k % kBranchLogSize] = d.resample ? 1 : 0;
     ctl->nDecisions = k + 1;
-    return resample;
 }
 
-// One wavefront, no LDS, no barrier: lane l owns the chunks [l*per, (l+1)*per) (per = 1 up to 16.7 M particles).
-// chunkBase is built to be non-decreasing by construction: lane bases by a SEQUENTIAL prefix over the 64 lane
-// totals, values inside a lane by sequential adds capped at the next lane's base.
-template <bool LOCAL_ONLY>
-__global__ __launch_bounds__(64) void k_loc_decide(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
-                                                  double* __restrict__ chunkBase, int numChunks, long long n,
-                                                  float range, RngKey key, int force,
-                                                  unsigned char* __restrict__ branchLog)
+__device__ __forceinline__ bool decide_scalars(LocCtl* __restrict__ ctl, const double (&tot)[7], long long n, float range,
+                                               const RngKey& key, int force, unsigned char* __restrict__ branchLog)
 {
-    const int lane = threadIdx.x;
+    const Decision d = decide_compute(tot, n, range, key, force);
+    decide_commit(ctl, d, branchLog);
+    return d.resample;
+}
+
+// Prefix over the chunk sums by ONE wavefront, no LDS, no barrier: lane l owns the chunks [l*per, (l+1)*per) (per = 1
+// up to 16.7 M particles).  The chunk bases are non-decreasing by construction: lane bases by a SEQUENTIAL prefix over
+// the 64 lane totals, values inside a lane by sequential adds capped at the next lane's base.  put(c, v) receives
+// base c for c in [0, numChunks]; tot[] the seven totals (in every lane).
+template <typename Put>
+__device__ __forceinline__ void chunk_prefix(const double* __restrict__ chunkSums, int numChunks, double (&tot)[7], Put put)
+{
+    const int lane = threadIdx.x & 63;
     const int per = (numChunks + 63) / 64;
     const int begin = min(lane * per, numChunks), end = min(begin + per, numChunks);
-
     double loc[7] = { 0, 0, 0, 0, 0, 0, 0 };
     for (int c = begin; c < end; ++c) {
         const double* p = chunkSums + (size_t)c * kSumsPerTile;
@@ -295,20 +311,28 @@ __global__ __launch_bounds__(64) void k_loc_decide(LocCtl* __restrict__ ctl, con
         run += t;
         if (l == lane) nextBase = run;
     }
-    const double S = run;
     double v = laneBase;
     for (int c = begin; c < end; ++c) {
-        chunkBase[c] = v < nextBase ? v : nextBase;
+        put(c, v < nextBase ? v : nextBase);
         v += chunkSums[(size_t)c * kSumsPerTile];
     }
-    if (lane == 0) chunkBase[numChunks] = S;
-
-    double tot[7];
-    tot[0] = S;
+    if (lane == 0) put(numChunks, run);
+    tot[0] = run;
 #pragma unroll
     for (int k = 1; k < 7; ++k) tot[k] = wave_sum(loc[k]);
+}
 
-    if (lane != 0) return;
+// The decision of a shard's local pass (LOCAL_ONLY: the sums are published for the all-gather) or of a filter whose
+// resampling stays source-owned: one wavefront.
+template <bool LOCAL_ONLY>
+__global__ __launch_bounds__(64) void k_loc_decide(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
+                                                  double* __restrict__ chunkBase, int numChunks, long long n,
+                                                  float range, RngKey key, int force,
+                                                  unsigned char* __restrict__ branchLog)
+{
+    double tot[7];
+    chunk_prefix(chunkSums, numChunks, tot, [&](int c, double v) { chunkBase[c] = v; });
+    if (threadIdx.x != 0) return;
     if (LOCAL_ONLY) {
         // sharded filter: publish the local sums; the decision is taken after the all-gather
 #pragma unroll
@@ -391,6 +415,65 @@ __device__ __forceinline__ long long first_offspring_at(double b, double rStart,
     for (int it = 0; it < 8 && f > 0 && !(rStart + rStep * (double)(f - 1) < b); ++it) --f;
     for (int it = 0; it < 8 && f < n && (rStart + rStep * (double)f < b); ++it) ++f;
     return f;
+}
+
+// ------------------------------------------------------------------ decision + source map (unsharded filters)
+// The decision of an unsharded filter, whose resampling is destination-owned (resample_dest_tile below): besides the
+// scalars, a resampling step needs, for every destination tile d, the source tile that holds the ancestor of its
+// first offspring.  Finding it inside the big kernel puts two to four dependent loads in front of everything else a
+// workgroup does; here it is one thread per destination tile, all of them at once.  Grid: one workgroup of 256 threads
+// per chunk of 256 tiles.  EVERY workgroup computes the chunk prefix and the decision (a pure function of the chunk
+// sums: same values everywhere) and keeps the chunk bases in LDS; workgroup 0 alone writes them, and the control block.
+__global__ __launch_bounds__(kThreads) void k_loc_decide_map(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
+                                                            double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
+                                                            int* __restrict__ srcTileOf, int numChunks, int numTiles, long long n,
+                                                            float range, RngKey key, int force,
+                                                            unsigned char* __restrict__ branchLog)
+{
+    __shared__ double base[kMaxChunks + 1];
+    __shared__ double dec[4];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        double tot[7];
+        const bool first = blockIdx.x == 0;
+        chunk_prefix(chunkSums, numChunks, tot, [&](int c, double v) { base[c] = v; if (first) chunkBase[c] = v; });
+        if (tid == 0) {
+            const Decision d = decide_compute(tot, n, range, key, force);
+            dec[0] = d.resample ? 1.0 : 0.0; dec[1] = d.rStart; dec[2] = d.rStep; dec[3] = d.S;
+            if (first) {
+                decide_commit(ctl, d, branchLog);
+                if (!d.resample) {  // the streaming pass's sums are the pose sums of the (unnormalised) current particles
+                    ctl->pose[0] = tot[0]; ctl->pose[1] = tot[4]; ctl->pose[2] = tot[5]; ctl->pose[3] = tot[6];
+                    ctl->pose[4] = tot[2]; ctl->pose[5] = tot[3];
+                }
+                ctl->shardBase = 0.0; ctl->shardEnd = tot[0];
+                ctl->outBegin = 0; ctl->outEnd = n; ctl->selfBegin = 0; ctl->selfEnd = n; ctl->nGlobal = n;
+            }
+        }
+    }
+    __syncthreads();
+    if (dec[0] == 0.0) return;
+    const int d = blockIdx.x * kThreads + tid;
+    if (d >= numTiles) return;
+    const double rStart = dec[1], rStep = dec[2], S = dec[3];
+    const double u = rStart + rStep * (double)((long long)d * kTile);   // pfResample.c:71 at the tile's first offspring
+    // first chunk whose end value exceeds u, then the first tile inside it (the last tile if u is beyond every end value)
+    int lo = 0, hi = numChunks;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (base[mid + 1] > u) hi = mid; else lo = mid + 1;
+    }
+    int t = numTiles - 1;
+    if (lo < numChunks) {
+        int a = lo * kChunkTiles, b = (a + kChunkTiles < numTiles) ? a + kChunkTiles : numTiles;
+        const int last = b - 1;
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (tile_start_cdf(base, tileIncl, mid + 1, 0.0, S) > u) b = mid; else a = mid + 1;
+        }
+        t = a < last ? a : last;
+    }
+    srcTileOf[d] = t;
 }
 
 // ------------------------------------------------------------------ resample
@@ -733,7 +816,7 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
                 }
                 ot[m] = thi;
                 const float gx = ox[m] - ga.bx, gy = oy[m] - ga.by, gz = oz[m] - ga.bz;
-                const float pRange = sqrtf(gx * gx + gy * gy + gz * gz);
+                const float pRange = sqrt_rn(gx * gx + gy * gy + gz * gz);
                 if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
                 ow[m] = wi;
                 acc[0] += cdf_weight(wi);
@@ -783,24 +866,256 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
     store_piece(carryTile, carry);
 }
 
+// ------------------------------------------------------------------ destination-owned resampling (unsharded filters)
+// The kernels above give a workgroup a SOURCE tile and let it produce however many offspring that tile's weight calls
+// for: simple, and what a sharded filter needs (offspring are produced where their ancestors live), but the work per
+// workgroup is as uneven as the weights -- a tile worth 1100 offspring runs a second round for 76 of them, a tile of
+// gated-out particles idles -- and the sums per destination tile have to be pieced together afterwards.  An unsharded
+// filter can turn it round: workgroup d produces offspring [1024 d, 1024 d + 1024), whatever ancestors they have.
+//   * the source tile that holds the ancestor of its first unresolved offspring is found by one wavefront with a
+//     64-ary search over the chunk bases and the in-chunk tile prefixes (2 to 4 dependent loads);
+//   * that tile's CDF is rebuilt in LDS from its weights (4 B per source particle; integer offsets, build_tile_cdf)
+//     and every offspring whose u_i lies below the tile's end value finds its ancestor in it; typically two source
+//     tiles cover a destination tile, a heavy ancestor region takes one, a stretch of light particles several;
+//   * the ancestors' x, y, z, theta are gathered straight from global memory (sorted indices: a wavefront's gathers
+//     fall into a few cache lines), the offspring are formed and, in the deferred form, deposited on, exactly as in
+//     resample_deposit_tile; all stores are aligned float4, the seven sums of the tile are reduced once and written
+//     where the streaming pass would have written them.
+// Every workgroup does the same amount of arithmetic (1024 offspring), which is what the kernel is bound by.
+// Selection rule, Philox counters and arithmetic are those of k_loc_resample: same particles, bit for bit.
+template <typename Pred>
+__device__ __forceinline__ int wave_first_true(int a, int b, Pred pred)
+{   // first index in [a, b) for which the monotone predicate holds (false ... false true ... true), b if none;
+    // called by all 64 lanes of one wavefront
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        const int len = b - a;
+        if (len <= 0) return b;
+        if (len <= 64) {
+            const bool p = (lane < len) && pred(a + lane);
+            const unsigned long long m = __ballot(p);
+            return m ? a + (int)__builtin_ctzll(m) : b;
+        }
+        const int stride = (len + 63) / 64;
+        int idx = a + (lane + 1) * stride - 1;              // last index of sub-range `lane`
+        idx = idx < b ? idx : b - 1;
+        const unsigned long long m = __ballot(pred(idx));
+        if (!m) return b;
+        const int sub = (int)__builtin_ctzll(m);
+        int last = a + (sub + 1) * stride - 1;
+        last = last < b ? last : b - 1;                     // the predicate holds there
+        a += sub * stride;
+        b = last;                                           // "none in [a, last)" then means `last` itself
+    }
+}
+
+// the source tile whose CDF span [tile start, tile end) holds position u: first tile whose end value exceeds u
+// (the last tile if there is none: offspring that fall off the end, and every offspring of a filter without weight)
+__device__ __forceinline__ int find_source_tile(const double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
+                                                int numChunks, int numTiles, double S, double u)
+{
+    int c = wave_first_true(0, numChunks, [&](int k) { return chunkBase[k + 1] > u; });
+    if (c >= numChunks) return numTiles - 1;
+    const int t0 = c * kChunkTiles, t1 = (t0 + kChunkTiles < numTiles) ? t0 + kChunkTiles : numTiles;
+    const int t = wave_first_true(t0, t1, [&](int k) { return tile_start_cdf(chunkBase, tileIncl, k + 1, 0.0, S) > u; });
+    return t < t1 ? t : t1 - 1;
+}
+
+#ifndef PF_OFFSPRING_UNROLL
+#define PF_OFFSPRING_UNROLL 4
+#endif
+struct DestLds {
+    double tab[kTile];          // CDF of the source tile at hand (integer form: the first half)
+    double park[7 * 64];
+    double red[4];
+};
+
+template <bool DEPOSIT, bool MOTION, bool RECORD, bool POSE>
+__device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const LocCtl* __restrict__ ctl,
+                                                   const double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
+                                                   int numTiles, int n, const RngKey& keyRs, const RespawnShell& sh,
+                                                   const RngKey& key, const Motion& mo, const Gate& ga,
+                                                   double* __restrict__ tileSums, int* __restrict__ ancOut,
+                                                   double* __restrict__ rsPart, const int* __restrict__ srcTileOf, DestLds& L)
+{
+    const int d = blockIdx.x, tid = threadIdx.x;
+    const int src = ctl->src, dst = ctl->dst;
+    const double rStart = ctl->rStart, rStep = ctl->rStep, S = ctl->S;
+    const float hTheta = ctl->htheta;
+    const int numSpawn = ctl->numSpawn;
+    const int numChunks = (numTiles + kChunkTiles - 1) / kChunkTiles;
+    const int lo = d * kTile;
+    const int cnt = (n - lo < kTile) ? n - lo : kTile;      // offspring of this tile that exist
+    const int k0 = tid * kPerThread;
+
+    double u[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) u[m] = rStart + rStep * (double)(lo + k0 + m);      // pfResample.c:71
+    int jg[4] = { 0, 0, 0, 0 };
+
+    // offspring below numSpawn are respawned on the range shell and need no ancestor (pfResample.c:75-76), unless the
+    // ancestors are being recorded (the reference selects one for them too, :70-72, before it overwrites them)
+    int next = RECORD ? 0 : numSpawn - lo;
+    next = next < 0 ? 0 : (next > cnt ? cnt : next);
+    const float* __restrict__ sw = bufs.a[src][0];
+    // Every wavefront works the tile sequence out for itself (uniform values, loads that hit the same lines): nothing
+    // but the CDF table goes through LDS, and its two barriers per tile are the only ones of the loop.
+    int tPrev = -1, tAhead = -1;
+    float4 wAhead = make_float4(0.f, 0.f, 0.f, 0.f);        // weights of the tile after the current one, loaded ahead
+    while (next < cnt) {                                    // uniform over the workgroup
+        // The source tile of offspring `next`.  For the tile's first offspring k_loc_decide_map has looked it up; later
+        // ones continue from the tile just used: its successors are probed 64 at a time (the next one, nearly always).
+        int t;
+        if (tPrev < 0 && next == 0) {
+            t = srcTileOf[d];
+        } else {
+            const double un = rStart + rStep * (double)(lo + next);
+            if (tPrev < 0) {
+                t = find_source_tile(chunkBase, tileIncl, numChunks, numTiles, S, un);
+            } else {
+                const int a = tPrev + 1, b = (a + 64 < numTiles) ? a + 64 : numTiles;
+                t = wave_first_true(a, b, [&](int k) { return tile_start_cdf(chunkBase, tileIncl, k + 1, 0.0, S) > un; });
+                if (t >= b) t = (b == numTiles) ? numTiles - 1 : find_source_tile(chunkBase, tileIncl, numChunks, numTiles, S, un);
+            }
+        }
+        const bool lastTile = t == numTiles - 1;
+        const double tileStart = tile_start_cdf(chunkBase, tileIncl, t, 0.0, S);
+        const double tileEnd = tile_start_cdf(chunkBase, tileIncl, t + 1, 0.0, S);
+        const float4 w4 = (t == tAhead) ? wAhead : *reinterpret_cast<const float4*>(sw + (size_t)t * kTile + k0);
+        if (!lastTile) {                                    // two source tiles per destination tile is the common case
+            tAhead = t + 1;
+            wAhead = *reinterpret_cast<const float4*>(sw + (size_t)tAhead * kTile + k0);
+        }
+        const int rem = n - t * kTile;
+        const int nValid = rem < kTile ? rem : kTile;
+        const float wq[4] = { w4.x, w4.y, w4.z, w4.w };
+        const bool small = build_tile_cdf(wq, tileStart, tileEnd, S, nValid, L.tab, L.red);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int k = k0 + m;
+            if (k >= next && k < cnt && (lastTile || u[m] < tileEnd))
+                jg[m] = t * kTile + tile_ancestor(L.tab, small, nValid, tileStart, u[m]);
+        }
+        // how far the tile got: the first offspring whose position is not below its end value (u is non-decreasing in k;
+        // offspring `next` itself lies below it, that is how the tile was chosen).  Arithmetic only, no memory.
+        next = lastTile ? cnt : wave_first_true(next + 1, cnt, [&](int k) { return !(rStart + rStep * (double)(lo + k) < tileEnd); });
+        tPrev = t;
+        // (no barrier here: the next tile's table is written behind the barrier of its scan, which every thread reaches
+        // only after it has finished searching this one)
+    }
+
+    const float* __restrict__ sx = bufs.a[src][1];
+    const float* __restrict__ sy = bufs.a[src][2];
+    const float* __restrict__ sz = bufs.a[src][3];
+    const float* __restrict__ st = bufs.a[src][4];
+    float ax[4], ay[4], az[4], at[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int j = jg[m];                                // 0 for respawned and pad offspring: a harmless read
+        ax[m] = sx[j]; ay[m] = sy[j]; az[m] = sz[j]; at[m] = st[j];
+    }
+
+    const bool smallTurn = mo.stdTheta <= 1e-4f;
+    double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    float ow[4], ox[4], oy[4], oz[4], ot[4];
+#pragma unroll PF_OFFSPRING_UNROLL
+    for (int m = 0; m < 4; ++m) {
+        const int k = k0 + m;
+        ow[m] = ox[m] = oy[m] = oz[m] = ot[m] = 0.0f;
+        if (k >= cnt) continue;                             // pad elements of the last tile stay zero
+        const uint64_t gi = (uint64_t)(lo + k);
+        if (lo + k < numSpawn) {
+            spawn_from_range(keyRs, gi, sh.bx, sh.by, sh.bz, sh.range, sh.stdRange, ox[m], oy[m], oz[m], ot[m]);
+        } else {
+            spawn_from_other(keyRs, gi, ax[m], ay[m], az[m], at[m], kHxyz, hTheta, ox[m], oy[m], oz[m], ot[m]);
+        }
+        float wi = 1.0f;
+        if (DEPOSIT) {
+            // the new deposit on the fresh offspring (weight 1): the body of k_loc_stream
+            float thi = ot[m], sn, cs;
+            if (MOTION) {
+                motion_particle(key, gi, mo, smallTurn, ox[m], oy[m], oz[m], thi, sn, cs);
+            } else {
+                thi = wrap_two_pi(thi);
+                sincos_bounded(thi, sn, cs);
+            }
+            ot[m] = thi;
+            const float gx = ox[m] - ga.bx, gy = oy[m] - ga.by, gz = oz[m] - ga.bz;
+            const float pRange = sqrt_rn(gx * gx + gy * gy + gz * gz);
+            if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
+            acc[0] += cdf_weight(wi);
+            acc[1] += wi * wi;
+            acc[2] += wi * cs;
+            acc[3] += wi * sn;
+            acc[4] += wi * ox[m];
+            acc[5] += wi * oy[m];
+            acc[6] += wi * oz[m];
+        } else if (POSE) {
+            float sn, cs;
+            sincos_bounded(ot[m], sn, cs);
+            acc[0] += ox[m]; acc[1] += oy[m]; acc[2] += oz[m]; acc[3] += cs; acc[4] += sn; acc[5] += 1.0;
+        }
+        ow[m] = wi;
+    }
+    const size_t e = (size_t)lo + k0;
+    *reinterpret_cast<float4*>(bufs.a[dst][0] + e) = make_float4(ow[0], ow[1], ow[2], ow[3]);
+    *reinterpret_cast<float4*>(bufs.a[dst][1] + e) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+    *reinterpret_cast<float4*>(bufs.a[dst][2] + e) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+    *reinterpret_cast<float4*>(bufs.a[dst][3] + e) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+    *reinterpret_cast<float4*>(bufs.a[dst][4] + e) = make_float4(ot[0], ot[1], ot[2], ot[3]);
+    if (RECORD) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (k0 + m < cnt) ancOut[lo + k0 + m] = jg[m];
+    }
+    if (DEPOSIT) {
+        const double r = block_sum_quads<7>(acc, L.park);
+        if (tid < 7) tileSums[(size_t)d * kSumsPerTile + tid] = r;
+    } else if (POSE) {
+        double pacc[6] = { acc[0], acc[1], acc[2], acc[3], acc[4], acc[5] };
+        const double r = block_sum_quads<6>(pacc, L.park);
+        if (tid < 6) rsPart[(size_t)d * kRsPerTile + tid] = r;
+    }
+}
+
+// The resampling a deposit decided on, on its own (undeferred filters; a pose query, download, ... that finds one pending).
+template <bool RECORD, bool POSE>
+__global__ __launch_bounds__(kThreads) void k_loc_resample_dest(LocBufs bufs, LocCtl* __restrict__ ctl,
+                                                               const double* __restrict__ chunkBase,
+                                                               const double* __restrict__ tileIncl, int* __restrict__ ancOut,
+                                                               int numTiles, int n, RngKey key, RespawnShell sh,
+                                                               double* __restrict__ rsPart, const int* __restrict__ srcTileOf)
+{
+    if (ctl->branch != 1) return;           // normalise-only step: nothing to do (wave-uniform exit)
+    __shared__ DestLds L;
+    if (POSE && blockIdx.x == 0 && threadIdx.x == 0) ctl->rsValid = 1;  // nobody in this launch reads it; k_loc_pose_tiles then exits
+    resample_dest_tile<false, false, RECORD, POSE>(bufs, ctl, chunkBase, tileIncl, numTiles, n, key, sh, key, Motion{}, Gate{},
+                                                   nullptr, ancOut, rsPart, srcTileOf, L);
+}
+
 // One deposit of an unsharded filter with deferred resampling, whichever way the previous decision went (it is
-// known on the device only): after a "resample" decision the offspring are produced and deposited on in one pass,
-// after a "normalise" decision this is k_loc_stream.  One launch instead of two of which one would exit at once
-// (an empty launch of 16 k workgroups plus its gap cost ~8 us of a 170 us deposit).  The two sides share the LDS.
+// known on the device only): after a "resample" decision the offspring are produced and deposited on in one pass
+// (workgroup d makes destination tile d), after a "normalise" decision this is k_loc_stream.  One launch instead of two
+// of which one would exit at once (an empty launch of 16 k workgroups plus its gap cost ~8 us of a 170 us deposit).
+// The two sides share the LDS.
+// Seven waves per SIMD (72 registers, no spill): the resampling side waits on dependent loads (source map -> weights
+// -> ancestors) before its arithmetic starts, and resident waves are what covers that (measured at N = 16 M:
+// 0.204 ms at 5 waves per SIMD, 0.190 at 6).
 template <bool MOTION>
-__global__ __launch_bounds__(kThreads) void k_loc_deposit(LocBufs bufs, const LocCtl* __restrict__ ctl,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_loc_deposit(LocBufs bufs, const LocCtl* __restrict__ ctl,
                                                          double* __restrict__ tileSums,
                                                          const double* __restrict__ chunkBase,
                                                          const double* __restrict__ tileIncl, int numTiles, int n,
                                                          RngKey keyRs, RespawnShell sh, RngKey key, Motion mo, Gate ga,
-                                                         PieceOut out)
+                                                         const int* __restrict__ srcTileOf)
 {
-    static_assert(sizeof(ResampleDepositLds) >= 7 * kThreads * sizeof(double), "stream side needs 7 * kThreads doubles");
-    __shared__ ResampleDepositLds L;
+    union DepositLds { DestLds dest; double red[7 * kThreads]; };
+    __shared__ DepositLds L;
     if (ctl->branch == 1)
-        resample_deposit_tile<MOTION, false>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga, out, StagePtrs{}, L);
+        resample_dest_tile<true, MOTION, false, false>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga, tileSums,
+                                                       nullptr, nullptr, srcTileOf, L.dest);
     else
-        stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, 0, key, mo, ga, reinterpret_cast<double*>(&L));
+        stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, 0, key, mo, ga, L.red);
 }
 
 // The same for one shard of a sharded filter (global indices, foreign offspring staged).  The host launches it
@@ -857,7 +1172,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_land(LocBufs bufs, const LocCt
                 sincos_bounded(th, sn, cs);
             }
             const float gx = x - ga.bx, gy = y - ga.by, gz = z - ga.bz;
-            const float pRange = sqrtf(gx * gx + gy * gy + gz * gz);
+            const float pRange = sqrt_rn(gx * gx + gy * gy + gz * gz);
             if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
             acc[0] += cdf_weight(wi);
             acc[1] += wi * wi;

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDim
         if (moving) motion_particle(key, (uint64_t)i * n + j, mo, smallTurn, r.x[k], r.y[k], r.z[k], r.th[k], sn[k], cs[k]);
         // pfMeasurement.c:142-147
         const float dx = tx - r.x[k], dy = ty - r.y[k], dz = tz - r.z[k];
-        const float pRange = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float pRange = sqrt_rn(dx * dx + dy * dy + dz * dz);
         if (fabsf(pRange - st.range) > st.thresh) r.w[k] *= st.minWeight;
     }
 
