@@ -167,6 +167,21 @@ int      pfx_loc_shard_pose_sums(pfx_loc* pf, double out[6]);   /* local sums of
 /* particleFilter.c:274-290 on caller-supplied (e.g. all-reduced) pose sums; 1 ok, 0 not initialised */
 int      pfx_loc_pose_from_sums(pfx_loc* pf, const double sums[6], double* t, float* x, float* y, float* z, float* theta);
 
+/* ---- one entry point that allocates nothing ----
+ * No counterpart in the reference (which never allocates: its scratch is a stack array, pfResample.c:35).  For callers
+ * that cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation:
+ * the pose reduction of getTagLoc (particleFilter.c:263-273; the kernels' code behind pfx_loc_shard_pose_sums) over the
+ * caller's own DEVICE arrays w, x, y, z, theta of n particles (16-byte aligned; true weight = w * wscale, as
+ * pfx_loc_device_arrays hands them out), six sums {w, w x, w y, w z, w cos theta, w sin theta} written to the caller's
+ * device buffer d_out6 by kernels enqueued on hip_stream (NULL = the default stream); feed them to pfx_loc_pose_from_sums.
+ * The per-tile partial sums, for which a filter allocates a buffer of its own, live in a static device array of the
+ * library: 4 MiB per GPU, held until the process ends, n <= 2^26 (larger n is refused with an error, nothing runs).
+ * Calls no hipMalloc / hipFree / allocating routine; the first call on a device looks the array's address up (do that
+ * once outside any graph capture).  All calls on one GPU share the array: calls that overlap there (different streams
+ * or threads) race and give wrong sums; successive calls need no clearing (every partial read was written by the same call). */
+int      pfx_pose_sums_noalloc(const float* d_w, const float* d_x, const float* d_y, const float* d_z, const float* d_theta,
+                               int64_t n, float wscale, double* d_out6, void* hip_stream, int device);
+
 /* ---- particleFilterSlam with runtime sizes, batched (BASELINE.json configs[4]) ----
  * A pfx_slam is a batch of `num_filters` independent SLAM filters on one GPU: each has n_tag tag particles
  * (reference: PF_N_TAG_SLAM = 100, particleFilter.h:19) and up to max_bcns (<= 32) beacons of n_tag x n_bcn

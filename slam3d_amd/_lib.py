@@ -100,6 +100,7 @@ def lib() -> C.CDLL:
     sig("pfx_loc_shard_cur", i, vp)
     sig("pfx_loc_shard_pose_sums", i, vp, pd_)
     sig("pfx_loc_pose_from_sums", i, vp, pd_, pd_, pf_, pf_, pf_, pf_)
+    sig("pfx_pose_sums_noalloc", i, vp, vp, vp, vp, vp, i64, f, vp, vp, i)
     sig("pfx_loc_of", vp, vp)
     sig("pfx_loc_sync_host", i, vp)
     sig("pfx_loc_release", None, vp)

@@ -1012,6 +1012,60 @@ extern "C" int pfx_loc_pose_from_sums(pfx_loc* pf, const double p[6], double* t,
     return 1;
 }
 
+// ------------------------------------------------------------------ pose sums without allocating anything
+// pfx_pose_sums_noalloc: the reduction behind getTagLoc (particleFilter.c:263-273; the same kernels' code as
+// pfx_loc_shard_pose_sums / pfx_loc_get_tag_loc after a resampling step) over a CALLER's device arrays, for callers that
+// cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The per-tile
+// partial sums, which every filter keeps in a buffer of its own (rsPart, allocated at creation), go to the static array
+// below: one copy per GPU, held until the process ends.
+constexpr long long kNoAllocMaxN = 1ll << 26;                          // 64 M particles -> 65 536 tiles -> 4 MiB
+constexpr int kNoAllocMaxTiles = (int)(kNoAllocMaxN / kTile);
+static __device__ __align__(256) double scratch[(size_t)kNoAllocMaxTiles * kRsPerTile];
+
+namespace {
+constexpr int kNoAllocMaxDevices = 64;
+double* g_scratchPtr[kNoAllocMaxDevices] = {};      // device address of `scratch` on each GPU (each holds its own copy)
+std::mutex g_scratchMu;
+
+// The array's name is a host-side stand-in, not a device address: ask the runtime once per device, with that device current.
+double* scratch_on_current_device(int device)
+{
+    std::lock_guard<std::mutex> lk(g_scratchMu);
+    if (!g_scratchPtr[device]) {
+        double* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) { set_error("hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e)); return nullptr; }
+        g_scratchPtr[device] = p;
+    }
+    return g_scratchPtr[device];
+}
+}  // namespace
+
+extern "C" int pfx_pose_sums_noalloc(const float* d_w, const float* d_x, const float* d_y, const float* d_z, const float* d_theta,
+                                     int64_t n, float wscale, double* d_out6, void* hip_stream, int device)
+{
+    clear_error();
+    if (n < 1 || n > kNoAllocMaxN) {
+        set_error("pfx_pose_sums_noalloc: n=%lld outside [1, %lld] (the static scratch array holds %d tiles of partial sums)",
+                  (long long)n, kNoAllocMaxN, kNoAllocMaxTiles);
+        return -2;
+    }
+    if (!d_w || !d_x || !d_y || !d_z || !d_theta || !d_out6) { set_error("pfx_pose_sums_noalloc: null pointer"); return -2; }
+    for (const float* p : { d_w, d_x, d_y, d_z, d_theta })
+        if ((uintptr_t)p % 16) { set_error("pfx_pose_sums_noalloc: the particle arrays must be 16-byte aligned"); return -2; }
+    if (device < 0 || device >= kNoAllocMaxDevices || device >= pfx_device_count()) { set_error("pfx_pose_sums_noalloc: no such device %d", device); return -2; }
+    DeviceGuard g(device);
+    double* part = scratch_on_current_device(device);
+    if (!part) return -1;
+    const int numTiles = (int)((n + kTile - 1) / kTile);
+    hipStream_t st = (hipStream_t)hip_stream;
+    // every partial the second kernel reads is written by the first: nothing of an earlier call survives into this one
+    hipLaunchKernelGGL(k_pose_tiles_raw, dim3(numTiles), dim3(kThreads), 0, st, d_w, d_x, d_y, d_z, d_theta, wscale, (long long)n, part);
+    if (check_launch("k_pose_tiles_raw")) return -1;
+    hipLaunchKernelGGL(k_pose_sum_raw, dim3(1), dim3(kThreads), 0, st, part, numTiles, d_out6);
+    return check_launch("k_pose_sum_raw");
+}
+
 // ------------------------------------------------------------------ kernel timing
 extern "C" int pfx_loc_profile_begin(pfx_loc* pf, int max_records)
 {

@@ -1192,21 +1192,31 @@ __global__ __launch_bounds__(kThreads) void k_loc_land(LocBufs bufs, const LocCt
 // by vector-ALU issue, for a result most deposits never ask for).  When a pose is asked for after a resampling
 // step, this pass computes the per-tile sums of w, wx, wy, wz, w cos, w sin over the current particles
 // (particleFilter.c:263-273); after a normalise-only step, or when the partials are already there, it exits.
-__global__ __launch_bounds__(kThreads) void k_loc_pose_tiles(LocBufs bufs, const LocCtl* __restrict__ ctl,
-                                                            double* __restrict__ rsPart, long long n)
+// body shared by k_loc_pose_tiles (the filter's own arrays) and k_pose_tiles_raw (a caller's arrays, pfx_pose_sums_noalloc)
+template <bool PADDED>
+__device__ __forceinline__ void pose_tile_body(const float* __restrict__ pw, const float* __restrict__ px, const float* __restrict__ py,
+                                               const float* __restrict__ pz, const float* __restrict__ pt, float wscale, long long n,
+                                               double* __restrict__ part, double* red)
 {
-    if (ctl->branch != 1 || ctl->rsValid) return;
-    __shared__ double red[6 * kThreads];
-    const int cur = ctl->cur;
-    const float wscale = ctl->wscale;
     const long long base = (long long)blockIdx.x * kTile + (long long)threadIdx.x * kPerThread;
-    const float4 w4 = *reinterpret_cast<const float4*>(bufs.a[cur][0] + base);
-    const float4 x4 = *reinterpret_cast<const float4*>(bufs.a[cur][1] + base);
-    const float4 y4 = *reinterpret_cast<const float4*>(bufs.a[cur][2] + base);
-    const float4 z4 = *reinterpret_cast<const float4*>(bufs.a[cur][3] + base);
-    const float4 t4 = *reinterpret_cast<const float4*>(bufs.a[cur][4] + base);
-    const float w[4] = { w4.x, w4.y, w4.z, w4.w }, x[4] = { x4.x, x4.y, x4.z, x4.w }, y[4] = { y4.x, y4.y, y4.z, y4.w };
-    const float z[4] = { z4.x, z4.y, z4.z, z4.w }, th[4] = { t4.x, t4.y, t4.z, t4.w };
+    float w[4], x[4], y[4], z[4], th[4];
+    if (PADDED || base + kPerThread <= n) {         // the filter's arrays are padded to whole tiles; a caller's need not be
+        const float4 w4 = *reinterpret_cast<const float4*>(pw + base);
+        const float4 x4 = *reinterpret_cast<const float4*>(px + base);
+        const float4 y4 = *reinterpret_cast<const float4*>(py + base);
+        const float4 z4 = *reinterpret_cast<const float4*>(pz + base);
+        const float4 t4 = *reinterpret_cast<const float4*>(pt + base);
+        w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w; x[0] = x4.x; x[1] = x4.y; x[2] = x4.z; x[3] = x4.w;
+        y[0] = y4.x; y[1] = y4.y; y[2] = y4.z; y[3] = y4.w; z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w;
+        th[0] = t4.x; th[1] = t4.y; th[2] = t4.z; th[3] = t4.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            const bool in = base + k < n;
+            w[k] = in ? pw[base + k] : 0.0f; x[k] = in ? px[base + k] : 0.0f; y[k] = in ? py[base + k] : 0.0f;
+            z[k] = in ? pz[base + k] : 0.0f; th[k] = in ? pt[base + k] : 0.0f;
+        }
+    }
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
@@ -1216,7 +1226,27 @@ __global__ __launch_bounds__(kThreads) void k_loc_pose_tiles(LocBufs bufs, const
         acc[0] += wi * x[k]; acc[1] += wi * y[k]; acc[2] += wi * z[k];
         acc[3] += wi * cs; acc[4] += wi * sn; acc[5] += cdf_weight(wi);
     }
-    block_sum_store<6>(acc, red, rsPart + (size_t)blockIdx.x * kRsPerTile);
+    block_sum_store<6>(acc, red, part + (size_t)blockIdx.x * kRsPerTile);
+}
+
+__global__ __launch_bounds__(kThreads) void k_loc_pose_tiles(LocBufs bufs, const LocCtl* __restrict__ ctl,
+                                                            double* __restrict__ rsPart, long long n)
+{
+    if (ctl->branch != 1 || ctl->rsValid) return;
+    __shared__ double red[6 * kThreads];
+    const int cur = ctl->cur;
+    pose_tile_body<true>(bufs.a[cur][0], bufs.a[cur][1], bufs.a[cur][2], bufs.a[cur][3], bufs.a[cur][4], ctl->wscale, n, rsPart, red);
+}
+
+// The same pass over a CALLER's device arrays, partials into a workspace the caller of the kernel names
+// (pfx_pose_sums_noalloc: the library's static scratch array).
+__global__ __launch_bounds__(kThreads) void k_pose_tiles_raw(const float* __restrict__ pw, const float* __restrict__ px,
+                                                            const float* __restrict__ py, const float* __restrict__ pz,
+                                                            const float* __restrict__ pt, float wscale, long long n,
+                                                            double* __restrict__ part)
+{
+    __shared__ double red[6 * kThreads];
+    pose_tile_body<false>(pw, px, py, pz, pt, wscale, n, part, red);
 }
 
 // ------------------------------------------------------------------ initial spawn (pfInit.c:20-25)
@@ -1263,14 +1293,14 @@ __global__ void k_loc_set_ctl(LocCtl* ctl, int cur, int branch, float wscale, in
 
 // Sum the per-tile pose partials of the last writer of the particles into ctl->pose (one workgroup).
 // After a normalise-only step k_loc_decide has already done this from the streaming pass.
-__global__ __launch_bounds__(kThreads) void k_loc_pose(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
-                                                      const double* __restrict__ rsPart, int numTiles, long long n)
+// fromPartials: per-tile {x y z cos sin w} partials (pose pass, spawn, resample); else the streaming pass's tile sums.
+__device__ __forceinline__ void pose_sum_body(const double* __restrict__ tileSums, const double* __restrict__ rsPart, bool fromPartials,
+                                              int numTiles, double (&acc)[6], double* red)
 {
-    __shared__ double red[4 * 6];
-    const int branch = ctl->branch;
-    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = 0.0;
     for (int t = threadIdx.x; t < numTiles; t += kThreads) {
-        if (branch == 1) {
+        if (fromPartials) {
             const double* p = rsPart + (size_t)t * kRsPerTile;
             acc[0] += p[5]; acc[1] += p[0]; acc[2] += p[1]; acc[3] += p[2]; acc[4] += p[3]; acc[5] += p[4];
         } else {
@@ -1279,10 +1309,31 @@ __global__ __launch_bounds__(kThreads) void k_loc_pose(LocCtl* __restrict__ ctl,
         }
     }
     block_sum<6>(acc, red);
+}
+
+__global__ __launch_bounds__(kThreads) void k_loc_pose(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
+                                                      const double* __restrict__ rsPart, int numTiles, long long n)
+{
+    __shared__ double red[4 * 6];
+    const int branch = ctl->branch;
+    double acc[6];
+    pose_sum_body(tileSums, rsPart, branch == 1, numTiles, acc, red);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) ctl->pose[k] = acc[k];
         if (branch == 1) ctl->rsValid = 1;
+    }
+}
+
+// ... of k_pose_tiles_raw's partials, into the caller's six doubles {sum w, w x, w y, w z, w cos, w sin}
+__global__ __launch_bounds__(kThreads) void k_pose_sum_raw(const double* __restrict__ part, int numTiles, double* __restrict__ out6)
+{
+    __shared__ double red[4 * 6];
+    double acc[6];
+    pose_sum_body(nullptr, part, true, numTiles, acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out6[k] = acc[k];
     }
 }
 
