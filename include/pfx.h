@@ -216,6 +216,9 @@ int      pfx_slam_deposit_tag_vio_batch(pfx_slam* pf, const double* t, const flo
 int      pfx_slam_deposit_range_batch(pfx_slam* pf, const int32_t* slot, const float* range, const float* stdRange);
 int      pfx_slam_get_tag_loc_batch(pfx_slam* pf, double* t, float* x, float* y, float* z, float* theta);
 int      pfx_slam_get_bcn_loc_batch(pfx_slam* pf, const int32_t* slot, uint8_t* ok, double* t, float* x, float* y, float* z, float* theta);
+/* measurement aid: rows of the measured beacons that the last deposit only normalised (out[0]) / resampled (out[1]),
+ * filters whose tag particles it resampled (out[2]), filters in the batch (out[3]); synchronises the stream */
+int      pfx_slam_row_census(pfx_slam* pf, int64_t out[4]);
 /* state: tag arrays of n_tag floats; beacon arrays of n_tag * n_bcn floats, row i = pBcn[i][*] (particleFilter.h:86) */
 int      pfx_slam_download_tag(pfx_slam* pf, int f, float* w, float* x, float* y, float* z, float* theta);
 int      pfx_slam_upload_tag(pfx_slam* pf, int f, const float* w, const float* x, const float* y, const float* z, const float* theta);

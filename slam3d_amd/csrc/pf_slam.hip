@@ -566,6 +566,25 @@ extern "C" int pfx_slam_last_tag_branch(pfx_slam* pf, int f)
     return *h;
 }
 
+// What the last deposit did to the rows of the measured beacons (measurement aid: bench.py prices a deposit by it).
+// out[0] = rows that only normalised, out[1] = rows that resampled, out[2] = filters whose tag particles resampled (every
+// initialised beacon of those was force-resampled, pfResample.c:122-130), out[3] = filters that took part.  Synchronises.
+extern "C" int pfx_slam_row_census(pfx_slam* pf, int64_t out[4])
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    const size_t F = (size_t)pf->D.numFilters, nTag = (size_t)pf->D.nTag;
+    std::vector<int> flag(F * nTag), br(F + 1);
+    PF_HIP_OK(hipMemcpyAsync(flag.data(), pf->rowFlag, flag.size() * sizeof(int), hipMemcpyDeviceToHost, pf->stream));
+    PF_HIP_OK(hipMemcpyAsync(br.data(), pf->forcedList, (F + 1) * sizeof(int), hipMemcpyDeviceToHost, pf->stream));
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    out[0] = out[1] = 0;
+    for (int v : flag) { if (v > 0) ++out[1]; else ++out[0]; }
+    out[2] = br[F];
+    out[3] = (int64_t)F;
+    return 0;
+}
+
 // ------------------------------------------------------------------ state access (tests, checkpoints)
 namespace {
 int copy_rows(pfx_slam* pf, float* const dev[5], size_t base, int rows, int n, int stride, float* const host[5], bool toHost)

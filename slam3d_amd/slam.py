@@ -149,6 +149,13 @@ class DeviceSlamBatch:
     def sync(self):
         check(self._L.pfx_slam_sync(self._h), "pfx_slam_sync")
 
+    def row_census(self):
+        """(rows normalised, rows resampled, filters whose tags resampled, filters) of the last deposit"""
+        import ctypes as C
+        out = (C.c_int64 * 4)()
+        check(self._L.pfx_slam_row_census(self._h, out), "pfx_slam_row_census")
+        return tuple(int(v) for v in out)
+
     # -- per filter (the reference's operations)
     def reset(self, f: int, seed: int):
         check(self._L.pfx_slam_reset(self._h, f, int(seed) & 0xFFFFFFFF), "pfx_slam_reset")

@@ -26,9 +26,33 @@ def per_kernel(d, counter):
     return acc
 
 
+def slam(fetch, write):
+    """python tools/pmc_traffic.py FETCH_DIR WRITE_DIR slam -> profiles/pmc_traffic_slam.json (bench.py --workload config5)"""
+    out = {}
+    for pat, key in (("k_slam_gate_rows", "k_slam_gate_rows"), ("k_slam_tag(", "k_slam_tag"), ("k_slam_rows_forced", "k_slam_rows_forced")):
+        fk = [k for k in fetch if pat in k]
+        wk = [k for k in write if pat in k]
+        if not fk or not wk:
+            continue
+        m = min(len(fetch[fk[0]]), len(write[wk[0]]))
+        f = fetch[fk[0]][-m:]
+        w = write[wk[0]][-m:]
+        # the first launches of a run spawn the beacons: take the second half (steady deposits)
+        f, w = f[m // 2:], w[m // 2:]
+        rd = 2.0 * 1024.0 * sum(f) / len(f)
+        wr = 1024.0 * sum(w) / len(w)
+        out[key] = {"kernel": fk[0].split("(")[0], "launches": len(f), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                    "hbm_bytes_per_launch": rd + wr, "note": "FETCH_SIZE doubled (gfx950 wide-stream correction: float4 row loads)"}
+    with open("profiles/pmc_traffic_slam.json", "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out, indent=1))
+
+
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    if len(sys.argv) > 3 and sys.argv[3] == "slam":
+        return slam(fetch, write)
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 16000000
     out = {}
 
@@ -57,13 +81,15 @@ def main():
     put("stream", k, work(ls))
     k, ls = launches("k_loc_stream<false, true>")
     put("stream_static", k, work(ls))
-    k, ls = launches("k_loc_resample<false>")
+    k, ls = launches("k_loc_resample_dest<false")
     put("resample", k, work(ls))
     # k_loc_deposit is one kernel with two sides (deferred resampling + deposit, or streaming pass only; the previous
     # decision, on the device, picks).  With motion both sides read 20 B and write 20 B per particle and cannot be
     # told apart by traffic: reported together.  Without motion the streaming side writes only the weights (4 B).
     k, ls = launches("k_loc_deposit<true>")
-    put("resample_stream", k, work(ls), "; both sides of k_loc_deposit<motion> (each 20 B read + 20 B written per particle)")
+    put("resample_stream", k, work(ls), "; both sides of k_loc_deposit<motion> (streaming: 20 B read + 20 B written per particle; "
+        "resampling: source weights of the tiles a destination tile draws from + gathered ancestors read, 20 B written; the "
+        "doubling of FETCH_SIZE is calibrated for float4 streams, the dword gathers are covered by it only roughly)")
     if "stream" not in out and "resample_stream" in out:
         out["stream"] = dict(out["resample_stream"])
     k, ls = launches("k_loc_deposit<false>")
