@@ -188,7 +188,9 @@ __global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(double* __restrict__
         double* p = tileSums + (size_t)t * kSumsPerTile;
         if (pieces.sums != nullptr && ctl->branch == 1) {
             const int first = t * kTile, last = (first + kTile < pieces.n ? first + kTile : pieces.n) - 1;
-            if (first < pieces.hi && last >= pieces.lo) {           // some of the tile was produced here
+            // (hi > lo: a shard without weight produces nothing, and then no piece of this round exists for any tile --
+            // the head / tail slots would be those of an earlier resampling)
+            if (pieces.hi > pieces.lo && first < pieces.hi && last >= pieces.lo) {  // some of the tile was produced here
                 int h = pieces.headSlot[t], e = pieces.tailSlot[t];
                 h = h < 0 ? 0 : h;
                 e = e >= 2 * numTiles ? 2 * numTiles - 1 : e;

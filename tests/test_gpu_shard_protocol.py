@@ -3,8 +3,11 @@ process on one GPU: the collectives are plain tensor copies here (all-gather = c
 shard's table; shipping = copy a slice of one shard's staging area into another's landing area), so shard counts and
 imbalances that the multi-process tests (tests/test_sharded.py: 2-3 ranks over gloo) cannot reach are covered, on the
 real kernels.  Reference: the unsharded filter on the same GPU with the same seed -- the noise is keyed by global
-particle index and every shard takes the decision from the same gathered sums, so the particles must agree (float64
-sums associate differently, which may move an ancestor by one for an offspring within ~1e-16 of a CDF step)."""
+particle index and every shard takes the decision from the same gathered sums, so the particles must agree: the
+weight totals and the CDF are exact sums, hence weights and z are EQUAL whatever the shard count; the
+heading's jitter bandwidth comes from circular sums that associate differently, so theta -- and x, y through the
+rotation of the VIO delta -- may differ in their last bits.  One test compares the sharded kernels with the ORACLE
+directly."""
 import os
 import sys
 
@@ -122,12 +125,13 @@ class InProcessShards:
 
 
 def _compare(got, ref, n, tol=1e-6):
-    for k in range(5):
+    for k in (0, 3):
+        assert np.array_equal(got[k], ref[k]), k
+    for k in (1, 2, 4):
         d = np.abs(got[k] - ref[k])
         if k == 4:
             d = np.minimum(d, np.abs(d - 6.2831855))
-        bad = int((d > tol).sum())
-        assert bad <= max(2, n // 5000), (k, bad, float(d.max()))
+        assert d.max() <= 4 * tol, (k, float(d.max()))
 
 
 @pytest.mark.parametrize("world,n,pose_every", [(1, 50000, 3), (2, 50001, 1), (4, 100003, 4), (7, 200000, 5), (16, 70000, 2)])
@@ -148,6 +152,50 @@ def test_in_process_shards_match_unsharded(world, n, pose_every):
     assert 0 < sum(s.branches) < len(s.branches)
     if world > 1:
         assert s.moved > 0, "no offspring ever crossed a shard boundary"
+
+
+@pytest.mark.parametrize("world", [1, 4, 8])
+def test_sharded_kernels_against_the_oracle(ora, world):
+    """The sharded HIP filter against the CPU oracle itself (not against another HIP filter): identical uploaded
+    particles, four deposits of which at least two resample (narrow gates on a wide cloud); those after a resampling run
+    fused with it, offspring shipped between the shards.  Same decisions, same ancestors -- z, which is the ancestor's
+    z plus 0.1 x a Box-Muller normal keyed by the global index, agrees to 5e-6 for EVERY particle, which a single
+    differing ancestor would break -- weights equal, poses to 1e-4."""
+    from slam3d_amd import particlefilter as pfm
+    n = 40001
+    rs = np.random.RandomState(8)
+    x, y, z = (rs.uniform(-3, 3, n).astype(np.float32) for _ in range(3))
+    th = rs.uniform(0, 6.28, n).astype(np.float32)
+    w = np.where(rs.uniform(size=n) < 0.2, 1.0, 0.1).astype(np.float32)
+    s = InProcessShards(n, world, seed=31, slack=2.0)
+    o = ora.OracleLoc(n, rng_mode=ora.RNG_PHILOX, seed=31, acc=ora.ACC_F64)
+    for k, sh in enumerate(s.shards):
+        a, b = s.T[k], s.T[k + 1]
+        up = pfm.DeviceParticleFilterLoc._borrow(sh._h)
+        up.upload(w[a:b], x[a:b], y[a:b], z[a:b], th[a:b])
+        up.epoch = 9
+    o.set_particles(w, x, y, z, th)
+    o.set_initialized(1)
+    o.epoch = 9
+    deposits = [(1.0, (0.0, 0.0, 0.0), (0.5, 0.2, 0.1, 3.0, 0.2)), (1.2, (0.1, -0.05, 0.02), (-1.0, 0.7, 0.0, 2.5, 0.1)),
+                (1.4, (0.15, -0.02, 0.03), (0.3, 0.3, 0.0, 3.2, 0.3)), (1.6, (0.2, 0.0, 0.03), (1.0, -0.5, 0.2, 2.0, 0.1))]
+    for f in (s, o):
+        f.depositVio(0.9, 0.0, 0.0, 0.0, 0.0)
+    ob = []
+    for t, p, r in deposits:
+        for f in (s, o):
+            f.depositVio(t, p[0], p[1], p[2], 0.0)
+            f.depositRange(*r)
+        ob.append(int(o.last_stats()["branch"]))
+    pa, pb = s.getTagLoc(), o.getTagLoc()
+    got, exp = s.download(), o.arrays()
+    assert s.branches == ob and sum(ob) >= 2, (s.branches, ob)
+    assert np.abs(np.array(pa[2:], dtype=np.float64) - np.array(pb[2:], dtype=np.float64)).max() <= 1e-4
+    assert np.array_equal(got[0], exp[0])
+    for k in range(1, 4):
+        assert np.abs(got[k] - exp[k]).max() <= 5e-6, k
+    if world > 1:
+        assert s.moved > 0
 
 
 def test_concentrated_weight_one_shard_feeds_all():

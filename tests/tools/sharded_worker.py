@@ -31,6 +31,12 @@ def events(n_steps):
     return ev
 
 
+def concentrate(w, n, first_global):
+    """weight 1e-30 outside the global particles [n/8 + 10, n/4 - 10); w holds the particles from first_global on"""
+    g = np.arange(first_global, first_global + w.shape[0])
+    w[(g < n // 8 + 10) | (g >= n // 4 - 10)] = np.float32(1e-30)
+
+
 def drive(pf, evs, on_deposit=None, pose_every=1):
     """pose_every = K: the pose is read after every K-th deposit only, so that the deposits in between run with
     their resampling deferred (fused with the next deposit)"""
@@ -61,6 +67,9 @@ def main():
     ap.add_argument("--seed", type=int, default=123456789)
     ap.add_argument("--force", type=int, default=-1)
     ap.add_argument("--pose-every", type=int, default=1)
+    ap.add_argument("--concentrate", type=int, default=0,
+                    help="after the spawn, leave weight only on global particles [n/8 + 10, n/4 - 10): one shard of eight then "
+                         "feeds all the others (oracle backend)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
@@ -76,13 +85,16 @@ def main():
         from _oracle_shard import OracleShard
         factory = OracleShard
     dev = int(os.environ.get("LOCAL_RANK", "0")) if a.pg == "nccl" else 0
-    pf = ShardedLocFilter(a.n, seed=a.seed, device=dev, backend_factory=factory, stage_slack=1.0)
+    # staging area = slack x the shard's own size: a shard that feeds all eight needs room for seven shards' worth
+    pf = ShardedLocFilter(a.n, seed=a.seed, device=dev, backend_factory=factory, stage_slack=8.0 if a.concentrate else 1.0)
     pf.set_force_branch(a.force)
     branches, moved = [], []
 
     def tap(f):
         branches.append(-1 if f.last_branch is None else int(f.last_branch))
         moved.append(f.exchanged_particles)
+        if a.concentrate and len(branches) == 1:
+            concentrate(f.shard.pf.arrays()[0], a.n, f.T[rank])
     poses = drive(pf, events(a.steps), tap, a.pose_every)
     w, x, y, z, th = pf.download_local()
     np.savez(os.path.join(a.out, f"rank{rank}.npz"), w=w, x=x, y=y, z=z, th=th, poses=poses,
