@@ -225,6 +225,11 @@ int      pfx_slam_upload_tag(pfx_slam* pf, int f, const float* w, const float* x
 int      pfx_slam_download_bcn(pfx_slam* pf, int f, int slot, float* w, float* x, float* y, float* z, float* theta);
 int      pfx_slam_upload_bcn(pfx_slam* pf, int f, int slot, const float* w, const float* x, const float* y, const float* z,
                              const float* theta, int initialized);
+/* device pointers of the SoA state, for zero-copy views: tag arrays [filter][tagStride], beacon arrays
+ * [filter][slot][tag particle][rowStride], pending per-row weight factor [filter][slot][tag particle] (true beacon weight
+ * = w * factor of its row); dims = numFilters, maxBcns, nTag, nBcn, tagStride, rowStride.  Synchronises the stream; the
+ * pointers stay valid for the life of the batch (SLAM rows are resampled in place, there is no ping-pong). */
+int      pfx_slam_device_arrays(pfx_slam* pf, void* d_tag[5], void* d_bcn[5], void** d_row_scale, int32_t dims[6]);
 /* binding between the reference-layout structs and device filters */
 pfx_slam* pfx_slam_of(const particleFilterSlam_t* pf);                       /* NULL if the struct is not bound */
 int      pfx_slam_slot_of(const particleFilterSlam_t* pf, const bcn_t* bcn); /* -1 until the beacon's first deposit */

@@ -137,6 +137,7 @@ def lib() -> C.CDLL:
     sig("pfx_slam_deposit_range_batch", i, vp, vp, vp, vp)
     sig("pfx_slam_get_tag_loc_batch", i, vp, vp, vp, vp, vp, vp)
     sig("pfx_slam_get_bcn_loc_batch", i, vp, vp, vp, vp, vp, vp, vp, vp)
+    sig("pfx_slam_device_arrays", i, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32))
     sig("pfx_slam_row_census", i, vp, C.POINTER(i64))
     sig("pfx_slam_download_tag", i, vp, i, vp, vp, vp, vp, vp)
     sig("pfx_slam_upload_tag", i, vp, i, vp, vp, vp, vp, vp)

@@ -9,6 +9,7 @@
 #include "pf_host.h"
 
 #include "../../include/pfx.h"
+#include "../../include/pfStages.h"
 
 #include <hip/hip_ext.h>
 
@@ -1249,6 +1250,41 @@ extern "C" uint8_t particleFilterLoc_getTagLoc(const particleFilterLoc_t* pf, do
     const int rc = pfx_loc_get_tag_loc(h, t, x, y, z, theta);
     if (rc < 0) { fail("particleFilterLoc_getTagLoc"); return 0; }
     return (uint8_t)rc;
+}
+
+// ---- the Loc-level stage functions of the reference's internal headers (include/pfStages.h): forwards onto the GPU stages
+extern "C" void pfRandom_init(void)
+{   // pfRandom.c:56-60
+    if (!PF_SEED_SET) PF_SEED = (unsigned int)time(nullptr);
+}
+
+extern "C" void pfInit_initTagLoc(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
+{   // pfInit.c:20-25 (the caller sets pf->initialized, as particleFilter.c:188-189 does)
+    pfx_loc* h = must_be_bound(pf, "pfInit_initTagLoc");
+    if (!h) return;
+    if (pfx_loc_spawn_all(h, bx, by, bz, range, stdRange)) { fail("pfInit_initTagLoc"); return; }
+    h->initialized = pf->initialized != 0;
+}
+
+extern "C" void pfMeasurement_applyVioLoc(particleFilterLoc_t* pf, float dt, float dx, float dy, float dz, float ddist)
+{   // pfMeasurement.c:24-49
+    pfx_loc* h = must_be_bound(pf, "pfMeasurement_applyVioLoc");
+    if (!h) return;
+    if (pfx_loc_apply_vio(h, dt, dx, dy, dz, ddist)) fail("pfMeasurement_applyVioLoc");
+}
+
+extern "C" void pfMeasurement_applyRangeLoc(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
+{   // pfMeasurement.c:108-125
+    pfx_loc* h = must_be_bound(pf, "pfMeasurement_applyRangeLoc");
+    if (!h) return;
+    if (pfx_loc_apply_range(h, bx, by, bz, range, stdRange)) fail("pfMeasurement_applyRangeLoc");
+}
+
+extern "C" void pfResample_resampleLoc(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
+{   // pfResample.c:30-84
+    pfx_loc* h = must_be_bound(pf, "pfResample_resampleLoc");
+    if (!h) return;
+    if (pfx_loc_resample(h, bx, by, bz, range, stdRange)) fail("pfResample_resampleLoc");
 }
 
 extern "C" pfx_loc* pfx_loc_of(const particleFilterLoc_t* pf) { return bound(pf); }

@@ -585,6 +585,22 @@ extern "C" int pfx_slam_row_census(pfx_slam* pf, int64_t out[4])
     return 0;
 }
 
+// Device pointers of the batch's SoA state for zero-copy views (Python: DeviceSlamBatch.arrays_view): tag arrays
+// [filter][tagStride], beacon arrays [filter][slot][tag particle][rowStride] (= pBcn[i][j], particleFilter.h:86), and the
+// pending per-row weight factor [filter][slot][tag particle] (true beacon weight = w * rowScale of its row).
+// dims: numFilters, maxBcns, nTag, nBcn, tagStride, rowStride.  Synchronises the stream.
+extern "C" int pfx_slam_device_arrays(pfx_slam* pf, void* d_tag[5], void* d_bcn[5], void** d_row_scale, int32_t dims[6])
+{
+    clear_error();
+    DeviceGuard g(pf->device);
+    PF_HIP_OK(hipStreamSynchronize(pf->stream));
+    for (int k = 0; k < 5; ++k) { d_tag[k] = pf->P.tag[k]; d_bcn[k] = pf->P.bcn[k]; }
+    *d_row_scale = pf->rowScale;
+    const SlamDims& D = pf->D;
+    dims[0] = D.numFilters; dims[1] = D.maxBcns; dims[2] = D.nTag; dims[3] = D.nBcn; dims[4] = D.tagStride; dims[5] = D.rowStride;
+    return 0;
+}
+
 // ------------------------------------------------------------------ state access (tests, checkpoints)
 namespace {
 int copy_rows(pfx_slam* pf, float* const dev[5], size_t base, int rows, int n, int stride, float* const host[5], bool toHost)

@@ -88,6 +88,23 @@ def _fptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class DeviceArrayView:
+    """library-owned device memory behind the CUDA array interface (version 3; also what HIP builds of torch / cupy read)"""
+
+    def __init__(self, ptr: int, shape, typestr: str, strides=None):
+        self.ptr, self.shape = int(ptr), tuple(int(v) for v in shape)
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": typestr, "data": (self.ptr, False), "version": 3,
+                                         "strides": None if strides is None else tuple(int(v) for v in strides), "stream": None}
+
+
+class ParticleViews:
+    def __init__(self, w, x, y, z, theta, wscale=1.0):
+        self.w, self.x, self.y, self.z, self.theta, self.wscale = w, x, y, z, theta, float(wscale)
+
+    def __iter__(self):
+        return iter((self.w, self.x, self.y, self.z, self.theta))
+
+
 class DeviceParticleFilterLoc:
     """particleFilterLoc with runtime N on a chosen GPU (pfx_loc_*, include/pfx.h)."""
 
@@ -193,6 +210,15 @@ class DeviceParticleFilterLoc:
         ws = C.c_float()
         check(self._L.pfx_loc_device_arrays(self._h, ptrs, C.byref(ws)), "pfx_loc_device_arrays")
         return [int(p) for p in ptrs], float(ws.value)
+
+    def arrays_view(self) -> "ParticleViews":
+        """Zero-copy views of the current particles in HBM: five objects with __cuda_array_interface__ (float32, n
+        elements; torch.as_tensor(v, device="cuda") / cupy.asarray(v) wrap them without a copy) and the pending
+        normalisation factor: true weight = w * wscale (pfResample.c:80-82 is applied lazily).  A pending resampling is
+        materialised first and the filter's stream is synchronised.  Valid until the next deposit, upload or reset on
+        this filter (a resampling deposit switches to the other buffer of the ping-pong pair)."""
+        ptrs, ws = self.device_arrays()
+        return ParticleViews(*[DeviceArrayView(p, (self.n,), "<f4") for p in ptrs], wscale=ws)
 
     # -- the stages of a step
     def apply_vio(self, dt, dx, dy, dz, ddist):

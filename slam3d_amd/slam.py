@@ -149,6 +149,25 @@ class DeviceSlamBatch:
     def sync(self):
         check(self._L.pfx_slam_sync(self._h), "pfx_slam_sync")
 
+    def arrays_view(self):
+        """Zero-copy views of the whole batch in HBM (objects with __cuda_array_interface__, float32):
+        tag  = (w, x, y, z, theta), each of shape (filters, n_tag);
+        bcn  = (w, x, y, z, theta), each of shape (filters, max_bcns, n_tag, n_bcn) -- bcn[k][f, slot, i, j] is
+               pBcn[i][j] of that beacon (particleFilter.h:86);
+        row_scale of shape (filters, max_bcns, n_tag): true beacon weight = w * row_scale of its row (the normalisation
+               of pfResample.c:195-199 is applied lazily).
+        Rows are padded in memory (strides say so).  Synchronises the stream; valid for the life of the batch."""
+        import ctypes as C
+        from .particlefilter import DeviceArrayView
+        tag, bcn = (C.c_void_p * 5)(), (C.c_void_p * 5)()
+        rs = C.c_void_p()
+        dims = (C.c_int32 * 6)()
+        check(self._L.pfx_slam_device_arrays(self._h, tag, bcn, C.byref(rs), dims), "pfx_slam_device_arrays")
+        F, B, nT, nB, tS, rS = [int(v) for v in dims]
+        tags = tuple(DeviceArrayView(p, (F, nT), "<f4", (4 * tS, 4)) for p in tag)
+        bcns = tuple(DeviceArrayView(p, (F, B, nT, nB), "<f4", (4 * B * nT * rS, 4 * nT * rS, 4 * rS, 4)) for p in bcn)
+        return {"tag": tags, "bcn": bcns, "row_scale": DeviceArrayView(rs.value, (F, B, nT), "<f4")}
+
     def row_census(self):
         """(rows normalised, rows resampled, filters whose tags resampled, filters) of the last deposit"""
         import ctypes as C

@@ -14,7 +14,7 @@ INC = os.path.join(ROOT, "include")
 
 def _declared_functions():
     names = []
-    for h in ("particleFilter.h", "pfx.h"):
+    for h in ("particleFilter.h", "pfx.h", "pfStages.h"):
         src = open(os.path.join(INC, h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         src = re.sub(r"^\s*#.*$", "", src, flags=re.M)
@@ -80,3 +80,42 @@ def test_reference_callers_link_unchanged(tmp_path, src):
                            "-L", libdir, "-lparticlefilter", "-lm", f"-Wl,-rpath,{libdir}"])
     out = subprocess.check_output(["nm", "-u", str(exe)]).decode()
     assert "particleFilter" in out      # resolved from the shared library, not compiled in
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/particlefilter/cython/particlefilter_wrapper.pyx"),
+                    reason="the reference tree only exists in the build container")
+def test_reference_cython_wrapper_builds_against_the_library(tmp_path):
+    """the reference's Cython wrapper, its .pyx unchanged, built with the one Extension(...)
+    call given there -- no particlefilter/src/*.c, linked against libparticlefilter.so instead.  Compile + link + import
+    only (constructing a filter needs a GPU).  The .pyx is copied to a scratch directory because Cython writes its C file
+    next to it and the reference tree is read-only; nothing of it enters this repository."""
+    pytest.importorskip("Cython")
+    import shutil
+    from slam3d_amd import _lib
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    work = tmp_path / "cy"
+    (work / "particlefilter" / "cython").mkdir(parents=True)
+    shutil.copy("/root/reference/particlefilter/cython/particlefilter_wrapper.pyx", work / "particlefilter" / "cython")
+    (work / "setup.py").write_text(
+        "import numpy\nfrom setuptools import setup, Extension\nfrom Cython.Build import cythonize\n"
+        "ext = Extension('particlefilter',\n"
+        "                sources=['particlefilter/cython/particlefilter_wrapper.pyx'],\n"
+        f"                include_dirs=[{INC!r}, numpy.get_include()],\n"
+        f"                libraries=['particlefilter'], library_dirs=[{libdir!r}],\n"
+        f"                runtime_library_dirs=[{libdir!r}])\n"
+        "setup(name='particlefilter', ext_modules=cythonize([ext], language_level=3))\n")
+    r = subprocess.run([sys.executable, "setup.py", "-q", "build_ext", "--inplace"], cwd=work, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    built = [f for f in os.listdir(work) if f.startswith("particlefilter") and f.endswith(".so")]
+    assert built, os.listdir(work)
+    und = subprocess.check_output(["nm", "-D", "-u", str(work / built[0])]).decode()
+    for fn in ("particleFilterLoc_init", "particleFilterLoc_depositVio", "particleFilterLoc_depositRange",
+               "particleFilterLoc_depositRssi", "particleFilterLoc_getTagLoc", "particleFilterSeed_set"):
+        assert fn in und, fn                # resolved from the shared library, not compiled in
+    needed = subprocess.check_output(["readelf", "-d", str(work / built[0])]).decode()
+    assert "libparticlefilter.so" in needed
+    # the module imports (loads the library) and offers the reference wrapper's names (particlefilter_wrapper.pyx:27-49)
+    code = "import particlefilter as m; assert hasattr(m, 'ParticleFilterLoc') and hasattr(m, 'setSeed'); m.setSeed(5); print('ok')"
+    r = subprocess.run([sys.executable, "-c", code], cwd=work, capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, PYTHONPATH=str(work)))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
