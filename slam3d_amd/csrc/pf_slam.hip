@@ -800,6 +800,16 @@ void legacy_deposit(particleFilterSlam_t* pf, bcn_t* bcn, float range, float std
         h->fl[0].bcnInit[c] = allBcns[i]->initialized != 0;    // the struct's flag is authoritative
     }
     r.target = target;
+    if (!((r.activeMask >> target) & 1u)) {
+        // The measured beacon is not one of allBcns.  Every caller in the reference lists it (csvslam.c:78-85,
+        // slam3d-jni.c:52-70); the reference would then skip its VIO commit and, when the tag particles resample, leave
+        // its gated weights un-normalised (pfResample.c:122-130).  Here it is treated as listed: one rule for the fused
+        // row pass, stated in INTEGRATION.md.
+        VioAcc bv = vio_load(bcn);
+        vio_commit(bv, r.bcnDelta[target]);
+        vio_store(bcn, bv);
+        r.activeMask |= 1u << target;
+    }
     h->fl[0].bcnInit[r.target] = bcn->initialized != 0;
     if (slam_step(h, &r, 1)) { fail(fn); return; }
     bcn->initialized = 1;
