@@ -740,16 +740,19 @@ extern "C" int pfx_resample_indices_f64(const double* cdf, int64_t n, double rSt
 // ------------------------------------------------------------------ one filter sharded over several GPUs
 // The host side (slam3d_amd/sharded.py) owns the collectives; these entry points are the local halves of a
 // deposit.  Sequence per deposit on every rank (include/pfx.h has the long form):
-//   pfx_loc_shard_begin                      VIO commit; spawns on the first range
-//   no resampling pending:  pfx_loc_shard_stream            streaming pass + local prefix
-//   resampling pending:     pfx_loc_shard_produce(1)        offspring of the local ancestors, deposited on in the same
-//                                                           pass; the foreign ones staged as records
-//                           (records shipped to the owners' landing areas by the caller, e.g. RCCL send/recv)
-//                           pfx_loc_shard_land(1, lo, hi)   received records unpacked and deposited on
-//                           pfx_loc_shard_finish(lo, hi)    local prefix from the pieces
-//   (all-gather of the 8 local sums of every rank into pfx_loc_shard_all_ptr, by the caller)
-//   pfx_loc_shard_decide + pfx_loc_shard_plan  the global decision, identical on every rank; a "resample" stays pending
-// A pending resampling is materialised without a deposit (pose query, download) by produce(0) + shipping + land(0).
+//   pfx_loc_shard_begin(pf, beacon, range, std)   VIO commit; spawns on the first range (returns 1: nothing else follows)
+//   pfx_loc_shard_deposit(pf)                     the O(N) pass, launched without looking at the previous decision: after a
+//                                                 "resample" the offspring of the local ancestors are produced and deposited
+//                                                 on in the same pass (foreign ones staged as records), else the streaming pass
+//   pfx_loc_shard_plan(pf, &branch, F)            the previous decision (it has landed in pinned memory meanwhile)
+//   after a "resample":  (records shipped to the owners' landing areas by the caller, e.g. RCCL send/recv)
+//                        pfx_loc_shard_land(pf, 1, lo, hi)     received records unpacked and deposited on
+//                        pfx_loc_shard_finish(pf, 1, lo, hi)   local prefix from the pieces
+//   after a "normalise": pfx_loc_shard_finish(pf, 0, 0, 0)
+//   (all-gather of the 8 local sums of every rank, pfx_loc_shard_local_ptr -> pfx_loc_shard_all_ptr, by the caller)
+//   pfx_loc_shard_decide(pf)                      the global decision, identical on every rank; a "resample" stays pending
+// A pending resampling is materialised without a deposit (pose query, download) by pfx_loc_shard_plan,
+// pfx_loc_shard_produce(pf), shipping, pfx_loc_shard_land(pf, 0, lo, hi).
 extern "C" int pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64_t n_global, int64_t self_begin,
                                     int64_t stage_capacity)
 {
