@@ -436,6 +436,16 @@ def main():
     global POSE_EVERY_STEP
     POSE_EVERY_STEP = args.pose_every_step
 
+    # ONE line on stdout: libraries print banners there (RCCL announces its version when a communicator is created), so
+    # everything but the result goes to stderr and the result is written to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     import torch
     import torch.distributed as dist
 
@@ -462,7 +472,7 @@ def main():
         out = measure_slam(args.slam_filters, args.slam_bcns, args.steps, args.warmup, world, rank, local, dist, torch,
                            with_cpu=(world == 1 and not args.no_cpu_baseline))
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -540,9 +550,10 @@ def main():
                                      "the 5 % respawn; the estimate sits ~1 m off the truth and half the deposits resample"},
             "roofline": roof, "kernels": per, "cpu_baseline": cpu, "extra": extra,
         }
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
+        emit(out)
+    if world > 1 or force_sharded:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 
