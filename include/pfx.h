@@ -52,6 +52,10 @@ long long   pfx_error_count(void);                  /* failures swallowed since 
  * `stream_id` separates the noise of filters that share a seed (Philox key word 1). */
 pfx_loc* pfx_loc_create(int64_t n, uint32_t seed, uint32_t stream_id, int device);
 void     pfx_loc_destroy(pfx_loc* pf);
+/* A second filter with the same particles, VIO accumulator, seed, sub-stream and deposit count on the same GPU: under
+ * the same calls the two stay bit for bit alike (the reference's way to fork a filter is struct assignment,
+ * particleFilter.h:62-77: the struct is a POD).  Unsharded filters only; NULL on error. */
+pfx_loc* pfx_loc_clone(pfx_loc* src);
 int      pfx_loc_reset(pfx_loc* pf, uint32_t seed, uint32_t stream_id);   /* back to "not initialised" */
 int64_t  pfx_loc_n(const pfx_loc* pf);
 int      pfx_loc_device(const pfx_loc* pf);
@@ -237,8 +241,14 @@ int      pfx_slam_sync_host(particleFilterSlam_t* pf, bcn_t* bcn);           /* 
 void     pfx_slam_release(particleFilterSlam_t* pf);                         /* free the device side */
 
 /* ---- binding between the reference-layout structs and device filters ---- */
-pfx_loc* pfx_loc_of(const particleFilterLoc_t* pf);          /* NULL if the struct is not bound */
-int      pfx_loc_sync_host(particleFilterLoc_t* pf);         /* fill pf->pTag[] (AoS) from HBM */
+/* A particleFilterLoc_t stays a POD that may be assigned, memcpy-ed or stored (reference: the struct is the filter):
+ *   - a copy taken from a struct that has not been used since is given a device-side clone at its first call;
+ *   - a copy that is to be continued LATER (a checkpoint, also across processes) must be taken right after
+ *     pfx_loc_sync_host(): it is then continued from its own pTag[] -- in a filter of its own, or, when the bytes are
+ *     copied back over the live struct, in place;
+ *   - any other copy is refused at its first call with a message (pfx_last_error). */
+pfx_loc* pfx_loc_of(const particleFilterLoc_t* pf);          /* NULL if the struct (at this address) is not bound */
+int      pfx_loc_sync_host(particleFilterLoc_t* pf);         /* fill pf->pTag[] (AoS) from HBM: the struct is a full checkpoint */
 void     pfx_loc_release(particleFilterLoc_t* pf);           /* free the device side (the reference API has no destroy) */
 
 #ifdef __cplusplus

@@ -51,6 +51,7 @@ def lib() -> C.CDLL:
     sig("pfx_error_count", C.c_longlong)
     sig("pfx_loc_create", vp, i64, u32, u32, i)
     sig("pfx_loc_destroy", None, vp)
+    sig("pfx_loc_clone", vp, vp)
     sig("pfx_loc_reset", i, vp, u32, u32)
     sig("pfx_loc_n", i64, vp)
     sig("pfx_loc_device", i, vp)

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <new>
 #include <unordered_set>
+#include <unistd.h>
 #include <vector>
 
 using namespace pf;
@@ -150,6 +151,10 @@ struct pfx_loc {
     unsigned profMask = ~0u;        // kernel classes that are timed while profOn
     int profStride = 1;             // ... every profStride-th launch of a class (the first one after profile_begin included)
     long long profCount[PFX_K_COUNT] = {};
+    // reference-layout binding (particleFilterLoc_t): the number of state-changing operations so far, mirrored into the
+    // bound struct's record so that a copy of the struct can be told from the struct itself (see "POD copies" below)
+    unsigned long long ops = 0;
+    unsigned long long* opsMirror = nullptr;
 };
 
 static std::mutex g_mu;
@@ -190,6 +195,12 @@ struct ProfScope {
 };
 
 RngKey key_of(const pfx_loc* pf) { return RngKey{ pf->seed, pf->streamId, pf->epoch }; }
+
+void touch(pfx_loc* pf)
+{   // a state-changing operation
+    ++pf->ops;
+    if (pf->opsMirror) *pf->opsMirror = pf->ops;
+}
 
 int check_launch(const char* what)
 {
@@ -454,6 +465,7 @@ extern "C" void pfx_loc_destroy(pfx_loc* pf)
 extern "C" int pfx_loc_reset(pfx_loc* pf, uint32_t seed, uint32_t stream_id)
 {   // particleFilter.c:32-46: scalars zeroed, not initialised; the particle arrays are left as they are
     clear_error();
+    touch(pf);
     {
         DeviceGuard g(pf->device);
         if (materialise(pf)) return -1;
@@ -467,13 +479,56 @@ extern "C" int pfx_loc_reset(pfx_loc* pf, uint32_t seed, uint32_t stream_id)
     return 0;
 }
 
+namespace {
+int clone_device(pfx_loc* dst, pfx_loc* src)
+{   // every device array of an unsharded filter, so that the copy continues bit for bit as the original would
+    const size_t nt = (size_t)src->numTiles, nc = (size_t)src->numChunks;
+    struct { void* d; const void* s; size_t bytes; } cp[] = {
+        { dst->slab, src->slab, src->padded * 10 * sizeof(float) },
+        { dst->tileSums, src->tileSums, nt * kSumsPerTile * sizeof(double) },
+        { dst->rsPart, src->rsPart, nt * kRsPerTile * sizeof(double) },
+        { dst->tileIncl, src->tileIncl, nt * sizeof(double) },
+        { dst->chunkSums, src->chunkSums, nc * kSumsPerTile * sizeof(double) },
+        { dst->chunkBase, src->chunkBase, (nc + 1) * sizeof(double) },
+        { dst->srcTileOf, src->srcTileOf, nt * sizeof(int) },
+        { dst->branchLog, src->branchLog, (size_t)kBranchLogSize },
+        { dst->ctl, src->ctl, sizeof(LocCtl) },
+    };
+    for (const auto& c : cp) PF_HIP_OK(hipMemcpyAsync(c.d, c.s, c.bytes, hipMemcpyDeviceToDevice, dst->stream));
+    PF_HIP_OK(hipStreamSynchronize(dst->stream));
+    return 0;
+}
+}  // namespace
+
+extern "C" pfx_loc* pfx_loc_clone(pfx_loc* src)
+{
+    clear_error();
+    if (src->numShards != 1 || src->stageSlab) { set_error("pfx_loc_clone: a shard of a sharded filter cannot be cloned"); return nullptr; }
+    {
+        DeviceGuard g(src->device);
+        if (materialise(src)) return nullptr;
+        if (hipStreamSynchronize(src->stream) != hipSuccess) { set_error("pfx_loc_clone: the source filter's stream failed"); return nullptr; }
+    }
+    pfx_loc* c = pfx_loc_create(src->n, src->seed, src->streamId, src->device);
+    if (!c) return nullptr;
+    DeviceGuard g(src->device);
+    if (clone_device(c, src)) { pfx_loc_destroy(c); return nullptr; }
+    c->epoch = src->epoch;
+    c->initialized = src->initialized;
+    c->poseDirty = true;
+    c->force = src->force;
+    c->vio = src->vio;
+    c->deferEnabled = src->deferEnabled;
+    return c;
+}
+
 extern "C" int64_t pfx_loc_n(const pfx_loc* pf) { return pf->n; }
 extern "C" int pfx_loc_device(const pfx_loc* pf) { return pf->device; }
 extern "C" int pfx_loc_initialized(const pfx_loc* pf) { return pf->initialized ? 1 : 0; }
 extern "C" uint32_t pfx_loc_epoch(const pfx_loc* pf) { return pf->epoch; }
 extern "C" uint32_t pfx_loc_seed(const pfx_loc* pf) { return pf->seed; }
 extern "C" uint32_t pfx_loc_stream_id(const pfx_loc* pf) { return pf->streamId; }
-extern "C" void pfx_loc_set_epoch(pfx_loc* pf, uint32_t e) { pf->epoch = e; }
+extern "C" void pfx_loc_set_epoch(pfx_loc* pf, uint32_t e) { pf->epoch = e; touch(pf); }
 
 extern "C" int pfx_loc_set_stream(pfx_loc* pf, void* hip_stream)
 {
@@ -514,11 +569,13 @@ extern "C" int pfx_loc_set_deferred(pfx_loc* pf, int enable)
 extern "C" void pfx_loc_deposit_vio(pfx_loc* pf, double t, float x, float y, float z, float dist)
 {
     vio_deposit(pf->vio, t, x, y, z, dist);
+    touch(pf);
 }
 
 extern "C" int pfx_loc_deposit_range(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
 {   // particleFilter.c:178-191
     clear_error();
+    touch(pf);
     DeviceGuard g(pf->device);
     float d[5];
     pf->epoch++;
@@ -579,6 +636,7 @@ extern "C" int pfx_loc_upload(pfx_loc* pf, const float* w, const float* x, const
                               const float* theta, int64_t n, int initialized)
 {
     clear_error();
+    touch(pf);
     if (n != pf->n) { set_error("pfx_loc_upload: n=%lld but the filter holds %lld", (long long)n, pf->n); return -2; }
     DeviceGuard g(pf->device);
     const float* src[5] = { w, x, y, z, theta };
@@ -632,6 +690,7 @@ extern "C" int pfx_loc_device_arrays(pfx_loc* pf, void* d_ptrs[5], float* wscale
 extern "C" int pfx_loc_apply_vio(pfx_loc* pf, float dt, float dx, float dy, float dz, float ddist)
 {   // pfMeasurement.c:24-49 (always the full update, also for zero motion)
     clear_error();
+    touch(pf);
     DeviceGuard g(pf->device);
     const float d[5] = { dt, dx, dy, dz, ddist };
     if (materialise(pf)) return -1;
@@ -643,6 +702,7 @@ extern "C" int pfx_loc_apply_vio(pfx_loc* pf, float dt, float dx, float dy, floa
 extern "C" int pfx_loc_apply_range(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
 {   // pfMeasurement.c:108-125
     clear_error();
+    touch(pf);
     DeviceGuard g(pf->device);
     const float zero[5] = { 0, 0, 0, 0, 0 };
     if (materialise(pf)) return -1;
@@ -654,6 +714,7 @@ extern "C" int pfx_loc_apply_range(pfx_loc* pf, float bx, float by, float bz, fl
 extern "C" int pfx_loc_resample(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
 {   // pfResample.c:30-84
     clear_error();
+    touch(pf);
     DeviceGuard g(pf->device);
     const float zero[5] = { 0, 0, 0, 0, 0 };
     if (materialise(pf)) return -1;
@@ -666,6 +727,7 @@ extern "C" int pfx_loc_resample(pfx_loc* pf, float bx, float by, float bz, float
 extern "C" int pfx_loc_spawn_all(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
 {   // pfInit.c:20-25
     clear_error();
+    touch(pf);
     DeviceGuard g(pf->device);
     if (materialise(pf)) return -1;
     pf->poseDirty = true;
@@ -1151,24 +1213,122 @@ extern "C" int64_t pfx_loc_branch_log(pfx_loc* pf, uint8_t* out, int64_t cap, in
 namespace {
 
 // Binding record kept in the first bytes of pTagBuf (scratch in the reference, pfResample.c:72-74).
-struct LocStash { uint64_t magic; uint64_t self; pfx_loc* handle; };
-constexpr uint64_t kLocMagic = 0x70664C6F63484950ull;   // "pfLocHIP"
+//
+// POD copies.  In the reference the struct IS the filter: assigning it, memcpy-ing it or writing it to a file and
+// reading it back gives a second filter / a checkpoint.  Here the particles live in HBM, so the
+// record carries what is needed to honour that:
+//   * `ops` mirrors the device filter's count of state-changing operations.  A struct whose record names a live
+//     filter with the SAME count is an up-to-date copy: found at another address it gets a device-side clone of its own
+//     (pfx_loc_clone) and the two continue independently, bit for bit alike under the same calls;
+//   * a copy that is OLDER than the filter it was taken from (a checkpoint: the original went on), or whose filter is
+//     gone (another process, pfx_loc_release), can only be continued from its own pTag[]: that array is current iff
+//     pfx_loc_sync_host ran right before the copy was taken (`syncedOps == ops`).  Then the particles, the VIO scalars
+//     of the struct and the noise counters of the record are uploaded into a filter of its own (into the bound one
+//     when the bytes were copied back over the live struct: a roll-back in place);
+//   * anything else (a stale copy without the particles) is an error that says so.
+struct LocStash {
+    uint64_t magic, self;
+    pfx_loc* handle;
+    uint64_t process;               // the process `handle` belongs to
+    unsigned long long ops;         // handle->ops when this struct last went through the library
+    unsigned long long syncedOps;   // ... when pTag[] was last filled from HBM; kNeverSynced otherwise
+    uint32_t seed, streamId, epoch;
+    int64_t n;
+};
+constexpr uint64_t kLocMagic = 0x70664C6F63484951ull;   // "pfLocHIQ"
+constexpr unsigned long long kNeverSynced = ~0ull;
+static_assert(sizeof(LocStash) <= sizeof(tagParticle_t) * 8, "binding record must stay a small prefix of pTagBuf");
+
+const uint64_t g_process = (uint64_t)time(nullptr) * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)&g_live ^ ((uint64_t)getpid() << 32);
 
 LocStash* stash_of(const particleFilterLoc_t* pf) { return reinterpret_cast<LocStash*>(const_cast<tagParticle_t*>(pf->pTagBuf)); }
 
+bool handle_live(const LocStash* s)
+{
+    if (s->magic != kLocMagic || s->process != g_process) return false;
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_live.count(s->handle) != 0;
+}
+
+// strictly this struct, at this address, bound to a live filter (whatever its contents' age)
 pfx_loc* bound(const particleFilterLoc_t* pf)
 {
     const LocStash* s = stash_of(pf);
-    if (s->magic != kLocMagic || s->self != (uint64_t)(uintptr_t)pf) return nullptr;
-    std::lock_guard<std::mutex> lk(g_mu);
-    return g_live.count(s->handle) ? s->handle : nullptr;
+    return (handle_live(s) && s->self == (uint64_t)(uintptr_t)pf) ? s->handle : nullptr;
 }
 
-pfx_loc* must_be_bound(const particleFilterLoc_t* pf, const char* fn)
+int64_t legacy_n();
+int legacy_device();
+
+void note_state(LocStash* s, const pfx_loc* h)
 {
-    pfx_loc* h = bound(pf);
-    if (!h) { set_error("%s: struct %p was not initialised with particleFilterLoc_init (or was moved)", fn, (const void*)pf); fail(fn); }
-    return h;
+    s->ops = h->ops; s->seed = h->seed; s->streamId = h->streamId; s->epoch = h->epoch; s->n = h->n;
+}
+
+void bind(particleFilterLoc_t* pf, pfx_loc* h)
+{
+    LocStash* s = stash_of(pf);
+    s->magic = kLocMagic; s->self = (uint64_t)(uintptr_t)pf; s->handle = h; s->process = g_process;
+    s->syncedOps = kNeverSynced;
+    note_state(s, h);
+    h->opsMirror = &s->ops;
+}
+
+VioState vio_of(const particleFilterLoc_t* pf)
+{
+    VioState v;
+    v.firstT = pf->firstT; v.firstX = pf->firstX; v.firstY = pf->firstY; v.firstZ = pf->firstZ; v.firstDist = pf->firstDist;
+    v.lastT = pf->lastT; v.lastX = pf->lastX; v.lastY = pf->lastY; v.lastZ = pf->lastZ; v.lastDist = pf->lastDist;
+    return v;
+}
+
+// the particles of the struct's own pTag[] into `h` (a checkpoint being continued)
+int restore_from_struct(particleFilterLoc_t* pf, pfx_loc* h, const LocStash& was)
+{
+    const int64_t n = h->n;
+    std::vector<float> tmp((size_t)n * 5);
+    for (int64_t i = 0; i < n; ++i) {
+        tmp[i] = pf->pTag[i].w; tmp[n + i] = pf->pTag[i].x; tmp[2 * n + i] = pf->pTag[i].y;
+        tmp[3 * n + i] = pf->pTag[i].z; tmp[4 * n + i] = pf->pTag[i].theta;
+    }
+    if (pfx_loc_upload(h, &tmp[0], &tmp[n], &tmp[2 * n], &tmp[3 * n], &tmp[4 * n], n, pf->initialized ? 1 : 0)) return -1;
+    h->vio = vio_of(pf);
+    h->seed = was.seed; h->streamId = was.streamId; h->epoch = was.epoch;
+    return 0;
+}
+
+// the device filter behind `pf`, giving a copied struct a filter of its own first (see "POD copies" above)
+pfx_loc* must_be_bound(const particleFilterLoc_t* cpf, const char* fn)
+{
+    particleFilterLoc_t* pf = const_cast<particleFilterLoc_t*>(cpf);
+    LocStash* s = stash_of(pf);
+    if (s->magic != kLocMagic) {
+        set_error("%s: struct %p was not initialised with particleFilterLoc_init", fn, (const void*)pf);
+        fail(fn);
+        return nullptr;
+    }
+    const bool live = handle_live(s);
+    const bool here = s->self == (uint64_t)(uintptr_t)pf;
+    if (live && here && s->ops == s->handle->ops) return s->handle;             // the common case
+    const LocStash was = *s;
+    if (live && !here && was.ops == was.handle->ops) {
+        pfx_loc* c = pfx_loc_clone(was.handle);
+        if (!c) { fail(fn); return nullptr; }
+        bind(pf, c);
+        return c;
+    }
+    if (was.syncedOps == was.ops && was.n >= 1 && was.n <= PF_N_TAG_LOC) {
+        pfx_loc* h = (live && here) ? was.handle : pfx_loc_create(was.n, was.seed, was.streamId, legacy_device());
+        if (!h) { fail(fn); return nullptr; }
+        if (restore_from_struct(pf, h, was)) { if (!(live && here)) pfx_loc_destroy(h); fail(fn); return nullptr; }
+        bind(pf, h);
+        stash_of(pf)->syncedOps = h->ops;       // pTag[] is what the filter holds
+        return h;
+    }
+    set_error("%s: struct %p is a copy of a filter that has since moved on (or is gone) and does not hold its particles: "
+              "call pfx_loc_sync_host() before copying a struct that is to be continued later", fn, (const void*)pf);
+    fail(fn);
+    return nullptr;
 }
 
 int64_t legacy_n()
@@ -1190,6 +1350,7 @@ void sync_scalars(particleFilterLoc_t* pf, const pfx_loc* h)
     pf->firstDist = h->vio.firstDist;
     pf->lastT = h->vio.lastT; pf->lastX = h->vio.lastX; pf->lastY = h->vio.lastY; pf->lastZ = h->vio.lastZ;
     pf->lastDist = h->vio.lastDist;
+    note_state(stash_of(pf), h);
 }
 
 // The reference API has no destroy.  Device memory still bound at process exit is reclaimed by the
@@ -1216,9 +1377,8 @@ extern "C" void particleFilterLoc_init(particleFilterLoc_t* pf)
     } else {
         h = pfx_loc_create(legacy_n(), PF_SEED, sid, legacy_device());
         if (!h) { fail("particleFilterLoc_init"); return; }
-        LocStash* s = stash_of(pf);
-        s->magic = kLocMagic; s->self = (uint64_t)(uintptr_t)pf; s->handle = h;
     }
+    bind(pf, h);
     sync_scalars(pf, h);
 }
 
@@ -1306,6 +1466,8 @@ extern "C" int pfx_loc_sync_host(particleFilterLoc_t* pf)
         pf->pTag[i].z = tmp[3 * n + i]; pf->pTag[i].theta = tmp[4 * n + i];
     }
     sync_scalars(pf, h);
+    // from here until the next state-changing call the struct is a complete checkpoint (if it holds all the particles)
+    stash_of(pf)->syncedOps = (n <= PF_N_TAG_LOC) ? h->ops : kNeverSynced;
     return 0;
 }
 
@@ -1314,5 +1476,6 @@ extern "C" void pfx_loc_release(particleFilterLoc_t* pf)
     pfx_loc* h = bound(pf);
     if (!h) return;
     pfx_loc_destroy(h);
-    memset(stash_of(pf), 0, sizeof(LocStash));
+    // the record stays: a struct that was synced to the host can still be continued (from its pTag[])
+    stash_of(pf)->handle = nullptr;
 }

@@ -118,3 +118,126 @@ def test_errors_can_be_reported_instead_of_aborting():
         assert L.particleFilterLoc_getTagLoc(C.cast(unbound, C.c_void_p), C.byref(t), C.byref(x), C.byref(x), C.byref(x), C.byref(x)) == 0
     finally:
         L.pfx_set_abort_on_error(1)
+
+
+# ------------------------------------------------------------------ the struct stays a POD
+def _loc_calls(k0, k1):
+    """deposits k0..k1-1 of a small scene, as (function name, args)"""
+    import _synth
+    bx, truth, rng = _synth.synthetic_scene(k1)
+    out = []
+    for k in range(k0, k1):
+        out.append(("particleFilterLoc_depositVio", (10.0 + 0.1 * k, float(truth[k, 0]), float(truth[k, 1]), float(truth[k, 2]), 0.0)))
+        b = k % 8
+        out.append(("particleFilterLoc_depositRange", (float(bx[b, 0]), float(bx[b, 1]), float(bx[b, 2]), float(rng[k, 0]), 0.1)))
+        if k % 3 == 2:
+            b2 = (k + 1) % 8
+            out.append(("particleFilterLoc_depositRssi", (float(bx[b2, 0]), float(bx[b2, 1]), float(bx[b2, 2]), -55)))
+    return out
+
+
+def _run(L, p, calls):
+    """drive the struct at address p; returns the pose after every deposit"""
+    poses = []
+    t = C.c_double()
+    v = [C.c_float() for _ in range(4)]
+    for fn, args in calls:
+        getattr(L, fn)(p, *args)
+        if fn != "particleFilterLoc_depositVio":
+            ok = L.particleFilterLoc_getTagLoc(p, C.byref(t), *[C.byref(q) for q in v])
+            poses.append((int(ok), t.value) + tuple(q.value for q in v))
+    return poses
+
+
+def _particles(L, p, pfm):
+    h = L.pfx_loc_of(p)
+    assert h
+    return pfm.DeviceParticleFilterLoc._borrow(h).download()
+
+
+def test_struct_copy_gets_a_filter_of_its_own():
+    """`particleFilterLoc_t b = a;` (here: memmove of the bytes) forks the filter: both continue, alike bit for bit"""
+    from slam3d_amd import _lib, particlefilter as pfm
+    L = _lib.lib()
+    pfm.setSeed(97)
+    a = C.create_string_buffer(pfm.SIZEOF_LOC)
+    b = C.create_string_buffer(pfm.SIZEOF_LOC)
+    pa, pb = C.cast(a, C.c_void_p), C.cast(b, C.c_void_p)
+    L.particleFilterLoc_init(pa)
+    _run(L, pa, _loc_calls(0, 9))
+    C.memmove(b, a, pfm.SIZEOF_LOC)
+    assert L.pfx_loc_of(pb) is None                 # not bound yet: the copy is adopted at its first call
+    rest = _loc_calls(9, 24)
+    poses_b = _run(L, pb, rest)
+    hb = L.pfx_loc_of(pb)
+    assert hb and hb != L.pfx_loc_of(pa)
+    poses_a = _run(L, pa, rest)
+    assert poses_a == poses_b
+    for u, v in zip(_particles(L, pa, pfm), _particles(L, pb, pfm)):
+        assert np.array_equal(u, v)
+    L.pfx_loc_release(pa)
+    L.pfx_loc_release(pb)
+
+
+def test_struct_checkpoint_is_continued_from_its_own_particles():
+    """pfx_loc_sync_host, copy the bytes away, go on; later the stored bytes continue exactly as the original did from
+    there -- at a new address, copied back over the live struct, and after the original's device side is gone"""
+    from slam3d_amd import _lib, particlefilter as pfm
+    L = _lib.lib()
+    pfm.setSeed(98)
+    a = C.create_string_buffer(pfm.SIZEOF_LOC)
+    pa = C.cast(a, C.c_void_p)
+    L.particleFilterLoc_init(pa)
+    _run(L, pa, _loc_calls(0, 10))
+    assert L.pfx_loc_sync_host(pa) == 0
+    saved = bytes(a.raw)                                        # the checkpoint (could as well go to a file)
+    rest = _loc_calls(10, 26)
+    poses_a = _run(L, pa, rest)
+    final_a = _particles(L, pa, pfm)
+
+    def same_continuation(p):
+        poses = _run(L, p, rest)
+        # the first pose is formed from re-summed weights (w * N/s stored, instead of N/s applied to the sums)
+        assert np.allclose(np.array(poses[0]), np.array(poses_a[0]), rtol=0, atol=2e-6)
+        assert poses[1:] == poses_a[1:]
+        for u, v in zip(_particles(L, p, pfm), final_a):
+            assert np.array_equal(u, v)
+
+    # (1) at a new address, the original still alive and ahead
+    d = C.create_string_buffer(saved, pfm.SIZEOF_LOC)
+    pd = C.cast(d, C.c_void_p)
+    same_continuation(pd)
+    assert L.pfx_loc_of(pd) != L.pfx_loc_of(pa)
+    L.pfx_loc_release(pd)
+    # (2) rolled back in place: the live struct's bytes replaced by the checkpoint; it keeps its device filter
+    h = L.pfx_loc_of(pa)
+    C.memmove(a, saved, pfm.SIZEOF_LOC)
+    same_continuation(pa)
+    assert L.pfx_loc_of(pa) == h
+    # (3) the device side gone (as in another process)
+    L.pfx_loc_release(pa)
+    e = C.create_string_buffer(saved, pfm.SIZEOF_LOC)
+    pe = C.cast(e, C.c_void_p)
+    same_continuation(pe)
+    L.pfx_loc_release(pe)
+
+
+def test_stale_struct_copy_is_refused_with_a_message():
+    from slam3d_amd import _lib, particlefilter as pfm
+    L = _lib.lib()
+    pfm.setSeed(99)
+    a = C.create_string_buffer(pfm.SIZEOF_LOC)
+    pa = C.cast(a, C.c_void_p)
+    L.particleFilterLoc_init(pa)
+    _run(L, pa, _loc_calls(0, 4))
+    stale = C.create_string_buffer(bytes(a.raw), pfm.SIZEOF_LOC)         # no pfx_loc_sync_host before the copy
+    _run(L, pa, _loc_calls(4, 6))                                         # ... and the original moves on
+    L.pfx_set_abort_on_error(0)
+    try:
+        n0 = L.pfx_error_count()
+        L.particleFilterLoc_depositRange(C.cast(stale, C.c_void_p), 0.0, 0.0, 0.0, 1.0, 0.1)
+        assert L.pfx_error_count() == n0 + 1
+        assert b"pfx_loc_sync_host" in L.pfx_last_error()
+    finally:
+        L.pfx_set_abort_on_error(1)
+    L.pfx_loc_release(pa)
