@@ -104,6 +104,10 @@ __host__ __device__ __forceinline__ float uniform_nonzero(uint32_t word) { retur
 // sinf/cosf by at most 1 ulp (5.96e-8) on 4 % of arguments.
 __device__ __forceinline__ void sincos_bounded(float x, float& s, float& c)
 {
+#ifdef PF_EXP_HW_SINCOS         // timing experiment: the hardware sine / cosine (argument in revolutions)
+    const float rev = x * 0.15915494309189535f;
+    s = __builtin_amdgcn_sinf(rev); c = __builtin_amdgcn_cosf(rev);
+#else
     const float k = __builtin_rintf(x * 0.636619747f);              // nearest multiple of pi/2
     float r = __builtin_fmaf(k, -1.57079625129699707031e+00f, x);   // pi/2 = hi + mid + lo
     r = __builtin_fmaf(k, -7.54978941586159635335e-08f, r);
@@ -121,6 +125,7 @@ __device__ __forceinline__ void sincos_bounded(float x, float& s, float& c)
     const float so = odd ? pc : ps, co = odd ? ps : pc;
     s = __uint_as_float(__float_as_uint(so) ^ ((q & 2u) << 30));
     c = __uint_as_float(__float_as_uint(co) ^ (((q + 1u) & 2u) << 30));
+#endif
 }
 
 // ln(u) for u in [2^-31, 1]: the hardware log2 (1 ulp) times ln 2 carried in two floats
@@ -211,18 +216,29 @@ __device__ __forceinline__ void spawn_from_range(const RngKey& key, uint64_t ind
     theta = uniform01(next()) * 2.0f * kPi;
 }
 
-// pfInit.c:68-79 -- jittered copy of an ancestor (w = 1 is written by the caller)
+// pfInit.c:68-79 -- jittered copy of an ancestor (w = 1 is written by the caller).  In two halves, the four unit
+// normals (which depend on nothing but the counter) and their use, so that a kernel can have the first half done while
+// it waits for the ancestor to arrive from memory.
+__device__ __forceinline__ void jitter_normals(const RngKey& key, uint64_t index, float (&nj)[4])
+{
+    const u32x4 r = rng_block(key, P_JITTER, index, 0);
+    normal2(r.a, r.b, nj[0], nj[1]);
+    normal2(r.c, r.d, nj[2], nj[3]);
+}
+__device__ __forceinline__ void spawn_from_other_n(const float (&nj)[4], float ox, float oy, float oz, float oth,
+                                                   float hXyz, float hTheta, float& x, float& y, float& z, float& theta)
+{
+    x = ox + nj[0] * hXyz;
+    y = oy + nj[1] * hXyz;
+    z = oz + nj[2] * hXyz;
+    theta = wrap_two_pi(oth + nj[3] * hTheta);
+}
 __device__ __forceinline__ void spawn_from_other(const RngKey& key, uint64_t index, float ox, float oy, float oz, float oth,
                                                  float hXyz, float hTheta, float& x, float& y, float& z, float& theta)
 {
-    const u32x4 r = rng_block(key, P_JITTER, index, 0);
-    float dx, dy, dz, dth;
-    normal2(r.a, r.b, dx, dy);
-    normal2(r.c, r.d, dz, dth);
-    x = ox + dx * hXyz;
-    y = oy + dy * hXyz;
-    z = oz + dz * hXyz;
-    theta = wrap_two_pi(oth + dth * hTheta);
+    float nj[4];
+    jitter_normals(key, index, nj);
+    spawn_from_other_n(nj, ox, oy, oz, oth, hXyz, hTheta, x, y, z, theta);
 }
 
 // pfMeasurement.c:36-47 (Loc), :61-74 (SLAM tag), :90-104 (SLAM beacon) -- VIO motion of one particle: rotate the
@@ -230,17 +246,19 @@ __device__ __forceinline__ void spawn_from_other(const RngKey& key, uint64_t ind
 // sums need them).  The heading noise is stdTheta * n with |n| < 6.6: while that stays below 1e-3 rad
 // (smallTurn, decided once per launch from stdTheta <= 1e-4) the sine and cosine of the heading BEFORE the noise
 // follow from those after it by the angle-difference formulas to second order (error < 5e-11), which saves one
-// sincos per particle in kernels bound by vector-ALU issue.
+// sincos per particle in kernels bound by vector-ALU issue.  Also in two halves (the unit normals, their use).
 struct Motion { float dx, dy, dz, stdXyz, stdTheta; };
 
-__device__ __forceinline__ void motion_particle(const RngKey& key, uint64_t index, const Motion& mo, bool smallTurn,
-                                                float& x, float& y, float& z, float& th, float& sn, float& cs)
+__device__ __forceinline__ void vio_normals(const RngKey& key, uint64_t index, float (&nv)[4])
 {
     const u32x4 r = rng_block(key, P_VIO, index, 0);
-    float rx, ry, rz, rth;
-    normal2(r.a, r.b, rx, ry);
-    normal2(r.c, r.d, rz, rth);
-    const float d = mo.stdTheta * rth;
+    normal2(r.a, r.b, nv[0], nv[1]);
+    normal2(r.c, r.d, nv[2], nv[3]);
+}
+__device__ __forceinline__ void motion_particle_n(const float (&nv)[4], const Motion& mo, bool smallTurn,
+                                                  float& x, float& y, float& z, float& th, float& sn, float& cs)
+{
+    const float d = mo.stdTheta * nv[3];
     float s0, c0;
     if (smallTurn) {
         th = wrap_two_pi(th + d);
@@ -258,9 +276,16 @@ __device__ __forceinline__ void motion_particle(const RngKey& key, uint64_t inde
     }
     const float pDx = mo.dx * c0 - mo.dy * s0;
     const float pDy = mo.dx * s0 + mo.dy * c0;
-    x += pDx + mo.stdXyz * rx;
-    y += pDy + mo.stdXyz * ry;
-    z += mo.dz + mo.stdXyz * rz;
+    x += pDx + mo.stdXyz * nv[0];
+    y += pDy + mo.stdXyz * nv[1];
+    z += mo.dz + mo.stdXyz * nv[2];
+}
+__device__ __forceinline__ void motion_particle(const RngKey& key, uint64_t index, const Motion& mo, bool smallTurn,
+                                                float& x, float& y, float& z, float& th, float& sn, float& cs)
+{
+    float nv[4];
+    vio_normals(key, index, nv);
+    motion_particle_n(nv, mo, smallTurn, x, y, z, th, sn, cs);
 }
 
 // ---------------------------------------------------------------- wave / block reductions (wave = 64)
@@ -365,15 +390,39 @@ __device__ __forceinline__ double block_sum_quads(const double (&v)[K], double* 
     return r;
 }
 
+// Inclusive scan over the 64 lanes of a wavefront in six DPP steps, no LDS: row_shr 1, 2, 4, 8 inside each row of 16
+// lanes (a lane without a source adds the identity), then the last lane of rows 0 and 2 broadcast into rows 1 and 3
+// (row_bcast:15) and lane 31 into the upper half (row_bcast:31).  The sums it is used for are exact (integers, or
+// float64 sums of multiples of 2^-20), so the order of the additions does not show.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v)
+{
+    v += dpp_or_zero<0x111, 0xf>(v);        // row_shr:1
+    v += dpp_or_zero<0x112, 0xf>(v);        // row_shr:2
+    v += dpp_or_zero<0x114, 0xf>(v);        // row_shr:4
+    v += dpp_or_zero<0x118, 0xf>(v);        // row_shr:8
+    v += dpp_or_zero<0x142, 0xa>(v);        // row_bcast:15 -> rows 1 and 3
+    v += dpp_or_zero<0x143, 0xc>(v);        // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
 // Inclusive scan of one double per thread across a 256-thread block.  `lds` holds 4 doubles.
 __device__ __forceinline__ double block_inclusive_scan(double v, double* lds, double& block_total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double up = __shfl_up(v, off, 64);
-        if (lane >= off) v += up;
-    }
+    v = wave_inclusive_scan(v);
     if (lane == 63) lds[wave] = v;
     __syncthreads();
     const double w0 = lds[0], w1 = lds[1], w2 = lds[2], w3 = lds[3];
@@ -454,11 +503,7 @@ __device__ __forceinline__ int upper_bound_tile_u32(const uint32_t* tab, int n, 
 __device__ __forceinline__ uint32_t block_inclusive_scan_u32(uint32_t v, uint32_t* lds)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(v, off, 64);
-        if (lane >= off) v += up;
-    }
+    v = wave_inclusive_scan(v);
     if (lane == 63) lds[wave] = v;
     __syncthreads();
     uint32_t pre = 0;

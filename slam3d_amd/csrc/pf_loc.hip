@@ -117,7 +117,7 @@ struct pfx_loc {
     float deferArg[5] = { 0, 0, 0, 0, 0 };
     double* pieceSums = nullptr;    // 2 * numTiles * kSumsPerTile: per (source tile, destination tile) sums
     int* pieceSlots = nullptr;      // head slot [numTiles], tail slot [numTiles]
-    int* srcTileOf = nullptr;       // numTiles: source tile of the first offspring of every destination tile (k_loc_decide_map)
+    DestPlan* destPlan = nullptr;   // numTiles: source tile and tile bounds for every destination tile (k_loc_decide_map)
     LocCtl* ctl = nullptr;
     LocCtl* hostCtl = nullptr;      // pinned
     uint32_t seed = 0, streamId = 0, epoch = 0;
@@ -246,7 +246,7 @@ int launch_decide(pfx_loc* pf, float range, bool localOnly = false, bool pieces 
     else if (pf->numShards == 1 && !pf->stageSlab)
         // unsharded: decision + source map of the destination-owned resampling
         hipExtLaunchKernelGGL(k_loc_decide_map, dim3(pf->numChunks), dim3(kThreads), 0, pf->stream, nullptr, ps.b(), 0, pf->ctl,
-                              pf->chunkSums, pf->chunkBase, pf->tileIncl, pf->srcTileOf, pf->numChunks, pf->numTiles, pf->n, range,
+                              pf->chunkSums, pf->chunkBase, pf->tileIncl, pf->destPlan, pf->numChunks, pf->numTiles, pf->n, range,
                               key_of(pf), pf->force, pf->branchLog);
     else
         hipExtLaunchKernelGGL((k_loc_decide<false>), dim3(1), dim3(kDecideThreads), 0, pf->stream, nullptr, ps.b(), 0, pf->ctl,
@@ -264,7 +264,7 @@ int launch_resample(pfx_loc* pf, const RngKey& key, float bx, float by, float bz
 #define PF_LAUNCH_RSD(R, P) \
     hipExtLaunchKernelGGL((k_loc_resample_dest<R, P>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->chunkBase, \
                           pf->tileIncl, pf->recordAnc ? pf->anc : (int*)nullptr, pf->numTiles, (int)pf->n, key, sh, pf->rsPart, \
-                          pf->srcTileOf)
+                          pf->destPlan)
         if (pf->recordAnc) PF_LAUNCH_RSD(true, false);
         else if (pose) PF_LAUNCH_RSD(false, true);
         else PF_LAUNCH_RSD(false, false);
@@ -289,12 +289,12 @@ int launch_resample(pfx_loc* pf, const RngKey& key, float bx, float by, float bz
 int launch_deposit(pfx_loc* pf, bool motion, const Motion& mo, const Gate& ga)
 {
     ProfScope ps(pf, motion ? PFX_K_DEPOSIT : PFX_K_DEPOSIT_STATIC);
-    const dim3 grid(pf->numTiles), block(kThreads);
+    const dim3 grid((pf->numTiles + kDepositTiles - 1) / kDepositTiles), block(kThreads);
     const float* a = pf->deferArg;
     const RespawnShell sh{ a[0], a[1], a[2], a[3], a[4] };
 #define PF_LAUNCH_DEP(M) \
     hipExtLaunchKernelGGL((k_loc_deposit<M>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->tileSums, \
-                          pf->chunkBase, pf->tileIncl, pf->numTiles, (int)pf->n, pf->deferKey, sh, key_of(pf), mo, ga, pf->srcTileOf)
+                          pf->chunkBase, pf->tileIncl, pf->numTiles, (int)pf->n, pf->deferKey, sh, key_of(pf), mo, ga, pf->destPlan)
     if (motion) PF_LAUNCH_DEP(true);
     else PF_LAUNCH_DEP(false);
 #undef PF_LAUNCH_DEP
@@ -364,7 +364,7 @@ void free_device(pfx_loc* pf)
     if (pf->anc) hipFree(pf->anc);
     if (pf->pieceSums) hipFree(pf->pieceSums);
     if (pf->pieceSlots) hipFree(pf->pieceSlots);
-    if (pf->srcTileOf) hipFree(pf->srcTileOf);
+    if (pf->destPlan) hipFree(pf->destPlan);
     if (pf->branchLog) hipFree(pf->branchLog);
     if (pf->ctl) hipFree(pf->ctl);
     if (pf->hostCtl) hipHostFree(pf->hostCtl);
@@ -399,8 +399,8 @@ int alloc_device(pfx_loc* pf)
     PF_HIP_OK(hipMalloc((void**)&pf->pieceSlots, 2 * nt * sizeof(int)));
     PF_HIP_OK(hipMemsetAsync(pf->pieceSums, 0, 2 * nt * kSumsPerTile * sizeof(double), pf->stream));
     PF_HIP_OK(hipMemsetAsync(pf->pieceSlots, 0, 2 * nt * sizeof(int), pf->stream));
-    PF_HIP_OK(hipMalloc((void**)&pf->srcTileOf, nt * sizeof(int)));
-    PF_HIP_OK(hipMemsetAsync(pf->srcTileOf, 0, nt * sizeof(int), pf->stream));
+    PF_HIP_OK(hipMalloc((void**)&pf->destPlan, nt * sizeof(DestPlan)));
+    PF_HIP_OK(hipMemsetAsync(pf->destPlan, 0, nt * sizeof(DestPlan), pf->stream));
     PF_HIP_OK(hipMalloc((void**)&pf->branchLog, kBranchLogSize));
     PF_HIP_OK(hipMemsetAsync(pf->branchLog, 0, kBranchLogSize, pf->stream));
     PF_HIP_OK(hipMalloc((void**)&pf->ctl, sizeof(LocCtl)));
@@ -490,7 +490,7 @@ int clone_device(pfx_loc* dst, pfx_loc* src)
         { dst->tileIncl, src->tileIncl, nt * sizeof(double) },
         { dst->chunkSums, src->chunkSums, nc * kSumsPerTile * sizeof(double) },
         { dst->chunkBase, src->chunkBase, (nc + 1) * sizeof(double) },
-        { dst->srcTileOf, src->srcTileOf, nt * sizeof(int) },
+        { dst->destPlan, src->destPlan, nt * sizeof(DestPlan) },
         { dst->branchLog, src->branchLog, (size_t)kBranchLogSize },
         { dst->ctl, src->ctl, sizeof(LocCtl) },
     };

@@ -82,7 +82,7 @@ __device__ __forceinline__ long long first_offspring_at(double b, double rStart,
 template <bool MOTION, bool GATE>
 __device__ __forceinline__ void stream_tile(const LocBufs& bufs, const LocCtl* __restrict__ ctl,
                                             double* __restrict__ tileSums, long long n, long long idx0,
-                                            const RngKey& key, const Motion& mo, const Gate& ga, double* red)
+                                            const RngKey& key, const Motion& mo, const Gate& ga, double* red, int tile)
 {
     // idx0: global index of local particle 0 (0 unless the filter is one shard of a larger one); the
     // Philox counter uses the global index, so the noise does not depend on how the filter is sharded
@@ -94,7 +94,7 @@ __device__ __forceinline__ void stream_tile(const LocBufs& bufs, const LocCtl* _
     float* __restrict__ pz = bufs.a[cur][3];
     float* __restrict__ pt = bufs.a[cur][4];
 
-    const long long base = (long long)blockIdx.x * kTile + (long long)threadIdx.x * kPerThread;
+    const long long base = (long long)tile * kTile + (long long)threadIdx.x * kPerThread;
     const float4 w4 = *reinterpret_cast<const float4*>(pw + base);
     const float4 x4 = *reinterpret_cast<const float4*>(px + base);
     const float4 y4 = *reinterpret_cast<const float4*>(py + base);
@@ -150,7 +150,7 @@ __device__ __forceinline__ void stream_tile(const LocBufs& bufs, const LocCtl* _
         *reinterpret_cast<float4*>(pt + base) = make_float4(th[0], th[1], th[2], th[3]);
     }
 
-    block_sum_store<7>(acc, red, tileSums + (size_t)blockIdx.x * kSumsPerTile);
+    block_sum_store<7>(acc, red, tileSums + (size_t)tile * kSumsPerTile);
 }
 
 template <bool MOTION, bool GATE>
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
                                                         RngKey key, Motion mo, Gate ga)
 {
     __shared__ double red[7 * kThreads];
-    stream_tile<MOTION, GATE>(bufs, ctl, tileSums, n, idx0, key, mo, ga, red);
+    stream_tile<MOTION, GATE>(bufs, ctl, tileSums, n, idx0, key, mo, ga, red, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------ two-level prefix, level 1
@@ -419,6 +419,19 @@ __device__ __forceinline__ long long first_offspring_at(double b, double rStart,
     return f;
 }
 
+// What workgroup d of a destination-owned resampling needs before it can load anything else: the source tile t0 that
+// holds the ancestor of its first offspring, and the CDF values that bound tile t0 and its successors.  One 64-byte
+// record per destination tile, written by k_loc_decide_map: the workgroup reads it together with the control block
+// (one round trip) and then knows which weights to load; without it the tile bounds were two more dependent loads, and
+// a third for every further source tile.
+constexpr int kPlanEnds = 6;
+struct __attribute__((aligned(64))) DestPlan {
+    int t0, pad;
+    double start0;              // CDF value at the start of tile t0
+    double end[kPlanEnds];      // CDF value at the end of tile t0 + i (the total weight from the last tile on)
+};
+static_assert(sizeof(DestPlan) == 64, "one cache line per destination tile");
+
 // ------------------------------------------------------------------ decision + source map (unsharded filters)
 // The decision of an unsharded filter, whose resampling is destination-owned (resample_dest_tile below): besides the
 // scalars, a resampling step needs, for every destination tile d, the source tile that holds the ancestor of its
@@ -428,7 +441,7 @@ __device__ __forceinline__ long long first_offspring_at(double b, double rStart,
 // sums: same values everywhere) and keeps the chunk bases in LDS; workgroup 0 alone writes them, and the control block.
 __global__ __launch_bounds__(kThreads) void k_loc_decide_map(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
                                                             double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
-                                                            int* __restrict__ srcTileOf, int numChunks, int numTiles, long long n,
+                                                            DestPlan* __restrict__ plan, int numChunks, int numTiles, long long n,
                                                             float range, RngKey key, int force,
                                                             unsigned char* __restrict__ branchLog)
 {
@@ -475,7 +488,15 @@ __global__ __launch_bounds__(kThreads) void k_loc_decide_map(LocCtl* __restrict_
         }
         t = a < last ? a : last;
     }
-    srcTileOf[d] = t;
+    DestPlan P;
+    P.t0 = t; P.pad = 0;
+    P.start0 = tile_start_cdf(base, tileIncl, t, 0.0, S);
+#pragma unroll
+    for (int i = 0; i < kPlanEnds; ++i) {
+        const int e = t + i + 1;
+        P.end[i] = tile_start_cdf(base, tileIncl, e < numTiles ? e : numTiles, 0.0, S);
+    }
+    plan[d] = P;
 }
 
 // ------------------------------------------------------------------ resample
@@ -926,34 +947,48 @@ __device__ __forceinline__ int find_source_tile(const double* __restrict__ chunk
 #ifndef PF_OFFSPRING_UNROLL
 #define PF_OFFSPRING_UNROLL 4
 #endif
+#ifndef PF_DEPOSIT_TILES
+#define PF_DEPOSIT_TILES 1
+#endif
+#ifndef PF_NOISE_AHEAD1
+#define PF_NOISE_AHEAD1 1
+#endif
+#ifndef PF_NOISE_AHEAD2
+#define PF_NOISE_AHEAD2 1
+#endif
+constexpr int kDepositTiles = PF_DEPOSIT_TILES;     // destination tiles per workgroup of k_loc_deposit
 struct DestLds {
     double tab[kTile];          // CDF of the source tile at hand (integer form: the first half)
     double park[7 * 64];
     double red[4];
 };
 
-template <bool DEPOSIT, bool MOTION, bool RECORD, bool POSE>
+// NSUB: destination tiles per workgroup (consecutive ones: blockIdx.x * NSUB + s).  With two, the dependent loads in front
+// of the arithmetic (record -> weights -> ancestors) are paid once per 2048 offspring, the second tile's ancestors are in
+// flight while the first tile is computed, and three source tiles are scanned per workgroup instead of four.
+template <int NSUB, bool DEPOSIT, bool MOTION, bool RECORD, bool POSE>
 __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const LocCtl* __restrict__ ctl,
                                                    const double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
                                                    int numTiles, int n, const RngKey& keyRs, const RespawnShell& sh,
                                                    const RngKey& key, const Motion& mo, const Gate& ga,
                                                    double* __restrict__ tileSums, int* __restrict__ ancOut,
-                                                   double* __restrict__ rsPart, const int* __restrict__ srcTileOf, DestLds& L)
+                                                   double* __restrict__ rsPart, const DestPlan& P, DestLds& L)
 {
-    const int d = blockIdx.x, tid = threadIdx.x;
+    const int d0 = blockIdx.x * NSUB, tid = threadIdx.x;
     const int src = ctl->src, dst = ctl->dst;
     const double rStart = ctl->rStart, rStep = ctl->rStep, S = ctl->S;
     const float hTheta = ctl->htheta;
     const int numSpawn = ctl->numSpawn;
     const int numChunks = (numTiles + kChunkTiles - 1) / kChunkTiles;
-    const int lo = d * kTile;
-    const int cnt = (n - lo < kTile) ? n - lo : kTile;      // offspring of this tile that exist
-    const int k0 = tid * kPerThread;
+    const int lo = d0 * kTile;
+    const int cnt = (n - lo < NSUB * kTile) ? n - lo : NSUB * kTile;    // offspring of this workgroup that exist
+    const int k0 = tid * kPerThread;        // the thread's offspring: lo + s * kTile + k0 + m, s < NSUB, m < 4
 
-    double u[4];
+    int jg[NSUB][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) u[m] = rStart + rStep * (double)(lo + k0 + m);      // pfResample.c:71
-    int jg[4] = { 0, 0, 0, 0 };
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) jg[s][m] = 0;
 
     // offspring below numSpawn are respawned on the range shell and need no ancestor (pfResample.c:75-76), unless the
     // ancestors are being recorded (the reference selects one for them too, :70-72, before it overwrites them)
@@ -962,45 +997,88 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
     const float* __restrict__ sw = bufs.a[src][0];
     // Every wavefront works the tile sequence out for itself (uniform values, loads that hit the same lines): nothing
     // but the CDF table goes through LDS, and its two barriers per tile are the only ones of the loop.
-    int tPrev = -1, tAhead = -1;
+    int tPrev = P.t0 - 1, tAhead = -1;
     float4 wAhead = make_float4(0.f, 0.f, 0.f, 0.f);        // weights of the tile after the current one, loaded ahead
+    // The weights of the first two source tiles are asked for here, and while they are on their way the noise of the
+    // thread's first offspring is drawn (Philox and Box-Muller depend on the counter only); the noise of its second
+    // offspring is drawn while the ancestors are on their way, further down.  (kAhead offspring; NSUB == 1.)
+    constexpr int kAhead1 = (NSUB == 1 && !RECORD) ? PF_NOISE_AHEAD1 : 0;     // ... drawn while the weights are on their way
+    constexpr int kAhead = (NSUB == 1 && !RECORD) ? PF_NOISE_AHEAD1 + PF_NOISE_AHEAD2 : 0;
+    float nj[kAhead > 0 ? kAhead : 1][4], nv[kAhead > 0 ? kAhead : 1][4];
+    int tFirst = -1;
+    float4 wFirst = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kAhead > 0) {
+        tFirst = P.t0;
+        wFirst = *reinterpret_cast<const float4*>(sw + (size_t)tFirst * kTile + k0);
+        if (tFirst + 1 < numTiles) {
+            tAhead = tFirst + 1;
+            wAhead = *reinterpret_cast<const float4*>(sw + (size_t)tAhead * kTile + k0);
+        }
+#pragma unroll
+        for (int m = 0; m < kAhead1; ++m)
+            if (k0 + m < cnt) {
+                jitter_normals(keyRs, (uint64_t)(lo + k0 + m), nj[m]);
+                if (DEPOSIT && MOTION) vio_normals(key, (uint64_t)(lo + k0 + m), nv[m]);
+            }
+    }
+#ifdef PF_EXP_IDENTITY_ANC      // timing experiment: no selection at all, offspring k descends from particle k
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) jg[s][m] = (lo + s * kTile + k0 + m < n) ? lo + s * kTile + k0 + m : 0;
+    next = cnt;
+#endif
     while (next < cnt) {                                    // uniform over the workgroup
-        // The source tile of offspring `next`.  For the tile's first offspring k_loc_decide_map has looked it up; later
-        // ones continue from the tile just used: its successors are probed 64 at a time (the next one, nearly always).
-        int t;
-        if (tPrev < 0 && next == 0) {
-            t = srcTileOf[d];
-        } else {
-            const double un = rStart + rStep * (double)(lo + next);
-            if (tPrev < 0) {
-                t = find_source_tile(chunkBase, tileIncl, numChunks, numTiles, S, un);
-            } else {
-                const int a = tPrev + 1, b = (a + 64 < numTiles) ? a + 64 : numTiles;
-                t = wave_first_true(a, b, [&](int k) { return tile_start_cdf(chunkBase, tileIncl, k + 1, 0.0, S) > un; });
-                if (t >= b) t = (b == numTiles) ? numTiles - 1 : find_source_tile(chunkBase, tileIncl, numChunks, numTiles, S, un);
+        // The source tile of offspring `next`: the first tile from tPrev + 1 on whose end value exceeds its position (the
+        // last tile if there is none).  The record of this destination tile holds the end values of t0 .. t0 + 5, which is
+        // nearly always enough; beyond it the tile bounds are loaded, its successors probed 64 at a time.
+        const double un = rStart + rStep * (double)(lo + next);
+        int t = -1;
+        double tileStart = 0.0, tileEnd = 0.0;
+#pragma unroll
+        for (int i = 0; i < kPlanEnds; ++i) {
+            const int ti = P.t0 + i;
+            if (t < 0 && ti > tPrev && (ti >= numTiles - 1 || P.end[i] > un)) {
+                t = ti < numTiles - 1 ? ti : numTiles - 1;
+                tileStart = (i == 0) ? P.start0 : P.end[i - 1];
+                tileEnd = P.end[i];
             }
         }
+        if (t < 0) {
+            const int a = (tPrev + 1 > P.t0 + kPlanEnds) ? tPrev + 1 : P.t0 + kPlanEnds;
+            const int b = (a + 64 < numTiles) ? a + 64 : numTiles;
+            t = wave_first_true(a, b, [&](int k) { return tile_start_cdf(chunkBase, tileIncl, k + 1, 0.0, S) > un; });
+            if (t >= b) t = (b == numTiles) ? numTiles - 1 : find_source_tile(chunkBase, tileIncl, numChunks, numTiles, S, un);
+            tileStart = tile_start_cdf(chunkBase, tileIncl, t, 0.0, S);
+            tileEnd = tile_start_cdf(chunkBase, tileIncl, t + 1, 0.0, S);
+        }
         const bool lastTile = t == numTiles - 1;
-        const double tileStart = tile_start_cdf(chunkBase, tileIncl, t, 0.0, S);
-        const double tileEnd = tile_start_cdf(chunkBase, tileIncl, t + 1, 0.0, S);
-        const float4 w4 = (t == tAhead) ? wAhead : *reinterpret_cast<const float4*>(sw + (size_t)t * kTile + k0);
-        if (!lastTile) {                                    // two source tiles per destination tile is the common case
+        const float4 w4 = (t == tFirst) ? wFirst : (t == tAhead) ? wAhead : *reinterpret_cast<const float4*>(sw + (size_t)t * kTile + k0);
+        if (!lastTile && tAhead != t + 1) {                 // the next source tile is nearly always needed too
             tAhead = t + 1;
             wAhead = *reinterpret_cast<const float4*>(sw + (size_t)tAhead * kTile + k0);
         }
+        // how far the tile gets: the first offspring whose position is not below its end value (u is non-decreasing in k;
+        // offspring `next` itself lies below it, that is how the tile was chosen).  Arithmetic only, no memory.
+        const int upto = lastTile ? cnt : wave_first_true(next + 1, cnt, [&](int k) { return !(rStart + rStep * (double)(lo + k) < tileEnd); });
         const int rem = n - t * kTile;
         const int nValid = rem < kTile ? rem : kTile;
         const float wq[4] = { w4.x, w4.y, w4.z, w4.w };
         const bool small = build_tile_cdf(wq, tileStart, tileEnd, S, nValid, L.tab, L.red);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int k = k0 + m;
-            if (k >= next && k < cnt && (lastTile || u[m] < tileEnd))
-                jg[m] = t * kTile + tile_ancestor(L.tab, small, nValid, tileStart, u[m]);
+        for (int s = 0; s < NSUB; ++s) {
+            if (NSUB == 1 || (upto > s * kTile && next < (s + 1) * kTile)) {            // uniform: tile s has offspring here
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int k = s * kTile + k0 + m;
+                    if (k >= next && k < upto) {
+                        const double u = rStart + rStep * (double)(lo + k);             // pfResample.c:71
+                        jg[s][m] = t * kTile + tile_ancestor(L.tab, small, nValid, tileStart, u);
+                    }
+                }
+            }
         }
-        // how far the tile got: the first offspring whose position is not below its end value (u is non-decreasing in k;
-        // offspring `next` itself lies below it, that is how the tile was chosen).  Arithmetic only, no memory.
-        next = lastTile ? cnt : wave_first_true(next + 1, cnt, [&](int k) { return !(rStart + rStep * (double)(lo + k) < tileEnd); });
+        next = upto;
         tPrev = t;
         // (no barrier here: the next tile's table is written behind the barrier of its scan, which every thread reaches
         // only after it has finished searching this one)
@@ -1010,73 +1088,103 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
     const float* __restrict__ sy = bufs.a[src][2];
     const float* __restrict__ sz = bufs.a[src][3];
     const float* __restrict__ st = bufs.a[src][4];
-    float ax[4], ay[4], az[4], at[4];
+    float ax[NSUB][4], ay[NSUB][4], az[NSUB][4], at[NSUB][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int j = jg[m];                                // 0 for respawned and pad offspring: a harmless read
-        ax[m] = sx[j]; ay[m] = sy[j]; az[m] = sz[j]; at[m] = st[j];
-    }
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int j = jg[s][m];                         // 0 for respawned and pad offspring: a harmless read
+#ifdef PF_EXP_NO_GATHER         // timing experiment
+            ax[s][m] = (float)j * 1e-7f; ay[s][m] = ax[s][m] + 1.0f; az[s][m] = 1.5f; at[s][m] = ax[s][m];
+#else
+            ax[s][m] = sx[j]; ay[s][m] = sy[j]; az[s][m] = sz[j]; at[s][m] = st[j];
+#endif
+        }
 
-    const bool smallTurn = mo.stdTheta <= 1e-4f;
-    double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
-    float ow[4], ox[4], oy[4], oz[4], ot[4];
-#pragma unroll PF_OFFSPRING_UNROLL
-    for (int m = 0; m < 4; ++m) {
-        const int k = k0 + m;
-        ow[m] = ox[m] = oy[m] = oz[m] = ot[m] = 0.0f;
-        if (k >= cnt) continue;                             // pad elements of the last tile stay zero
-        const uint64_t gi = (uint64_t)(lo + k);
-        if (lo + k < numSpawn) {
-            spawn_from_range(keyRs, gi, sh.bx, sh.by, sh.bz, sh.range, sh.stdRange, ox[m], oy[m], oz[m], ot[m]);
-        } else {
-            spawn_from_other(keyRs, gi, ax[m], ay[m], az[m], at[m], kHxyz, hTheta, ox[m], oy[m], oz[m], ot[m]);
-        }
-        float wi = 1.0f;
-        if (DEPOSIT) {
-            // the new deposit on the fresh offspring (weight 1): the body of k_loc_stream
-            float thi = ot[m], sn, cs;
-            if (MOTION) {
-                motion_particle(key, gi, mo, smallTurn, ox[m], oy[m], oz[m], thi, sn, cs);
-            } else {
-                thi = wrap_two_pi(thi);
-                sincos_bounded(thi, sn, cs);
-            }
-            ot[m] = thi;
-            const float gx = ox[m] - ga.bx, gy = oy[m] - ga.by, gz = oz[m] - ga.bz;
-            const float pRange = sqrt_rn(gx * gx + gy * gy + gz * gz);
-            if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
-            acc[0] += cdf_weight(wi);
-            acc[1] += wi * wi;
-            acc[2] += wi * cs;
-            acc[3] += wi * sn;
-            acc[4] += wi * ox[m];
-            acc[5] += wi * oy[m];
-            acc[6] += wi * oz[m];
-        } else if (POSE) {
-            float sn, cs;
-            sincos_bounded(ot[m], sn, cs);
-            acc[0] += ox[m]; acc[1] += oy[m]; acc[2] += oz[m]; acc[3] += cs; acc[4] += sn; acc[5] += 1.0;
-        }
-        ow[m] = wi;
-    }
-    const size_t e = (size_t)lo + k0;
-    *reinterpret_cast<float4*>(bufs.a[dst][0] + e) = make_float4(ow[0], ow[1], ow[2], ow[3]);
-    *reinterpret_cast<float4*>(bufs.a[dst][1] + e) = make_float4(ox[0], ox[1], ox[2], ox[3]);
-    *reinterpret_cast<float4*>(bufs.a[dst][2] + e) = make_float4(oy[0], oy[1], oy[2], oy[3]);
-    *reinterpret_cast<float4*>(bufs.a[dst][3] + e) = make_float4(oz[0], oz[1], oz[2], oz[3]);
-    *reinterpret_cast<float4*>(bufs.a[dst][4] + e) = make_float4(ot[0], ot[1], ot[2], ot[3]);
-    if (RECORD) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            if (k0 + m < cnt) ancOut[lo + k0 + m] = jg[m];
-    }
-    if (DEPOSIT) {
-        const double r = block_sum_quads<7>(acc, L.park);
-        if (tid < 7) tileSums[(size_t)d * kSumsPerTile + tid] = r;
-    } else if (POSE) {
-        double pacc[6] = { acc[0], acc[1], acc[2], acc[3], acc[4], acc[5] };
-        const double r = block_sum_quads<6>(pacc, L.park);
-        if (tid < 6) rsPart[(size_t)d * kRsPerTile + tid] = r;
+    for (int m = kAhead1; m < kAhead; ++m)                  // while the ancestors are on their way
+        if (k0 + m < cnt) {
+            jitter_normals(keyRs, (uint64_t)(lo + k0 + m), nj[m]);
+            if (DEPOSIT && MOTION) vio_normals(key, (uint64_t)(lo + k0 + m), nv[m]);
+        }
+    const bool smallTurn = mo.stdTheta <= 1e-4f;
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+        const int d = d0 + s;
+        const int cntS = (cnt - s * kTile < kTile) ? cnt - s * kTile : kTile;   // <= 0: a second tile that does not exist
+        if (NSUB == 1 || cntS > 0) {                        // uniform
+        double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        float ow[4], ox[4], oy[4], oz[4], ot[4];
+#pragma unroll PF_OFFSPRING_UNROLL
+        for (int m = 0; m < 4; ++m) {
+            const int k = k0 + m;
+            ow[m] = ox[m] = oy[m] = oz[m] = ot[m] = 0.0f;
+            if (k >= cntS) continue;                        // pad elements of the last tile stay zero
+            const int g = lo + s * kTile + k;
+            const uint64_t gi = (uint64_t)g;
+            const bool ahead = m < kAhead;                  // this offspring's unit normals have been drawn already
+            if (g < numSpawn) {
+                spawn_from_range(keyRs, gi, sh.bx, sh.by, sh.bz, sh.range, sh.stdRange, ox[m], oy[m], oz[m], ot[m]);
+            } else if (ahead) {
+                spawn_from_other_n(nj[m < kAhead ? m : 0], ax[s][m], ay[s][m], az[s][m], at[s][m], kHxyz, hTheta, ox[m], oy[m], oz[m], ot[m]);
+            } else {
+                spawn_from_other(keyRs, gi, ax[s][m], ay[s][m], az[s][m], at[s][m], kHxyz, hTheta, ox[m], oy[m], oz[m], ot[m]);
+            }
+            float wi = 1.0f;
+            if (DEPOSIT) {
+                // the new deposit on the fresh offspring (weight 1): the body of k_loc_stream
+                float thi = ot[m], sn, cs;
+                if (MOTION && ahead) {
+                    motion_particle_n(nv[m < kAhead ? m : 0], mo, smallTurn, ox[m], oy[m], oz[m], thi, sn, cs);
+                } else if (MOTION) {
+                    motion_particle(key, gi, mo, smallTurn, ox[m], oy[m], oz[m], thi, sn, cs);
+                } else {
+                    thi = wrap_two_pi(thi);
+                    sincos_bounded(thi, sn, cs);
+                }
+                ot[m] = thi;
+                const float gx = ox[m] - ga.bx, gy = oy[m] - ga.by, gz = oz[m] - ga.bz;
+                const float pRange = sqrt_rn(gx * gx + gy * gy + gz * gz);
+                if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
+                acc[0] += cdf_weight(wi);
+                acc[1] += wi * wi;
+                acc[2] += wi * cs;
+                acc[3] += wi * sn;
+                acc[4] += wi * ox[m];
+                acc[5] += wi * oy[m];
+                acc[6] += wi * oz[m];
+            } else if (POSE) {
+                float sn, cs;
+                sincos_bounded(ot[m], sn, cs);
+                acc[0] += ox[m]; acc[1] += oy[m]; acc[2] += oz[m]; acc[3] += cs; acc[4] += sn; acc[5] += 1.0;
+            }
+            ow[m] = wi;
+        }
+        const size_t e = (size_t)lo + s * kTile + k0;
+#ifdef PF_EXP_NO_STORE          // timing experiment: the results stay alive, nothing is written
+        if (ow[0] + ox[1] + oy[2] + oz[3] + ot[0] == 12345.678f)
+#endif
+        {
+            *reinterpret_cast<float4*>(bufs.a[dst][0] + e) = make_float4(ow[0], ow[1], ow[2], ow[3]);
+            *reinterpret_cast<float4*>(bufs.a[dst][1] + e) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+            *reinterpret_cast<float4*>(bufs.a[dst][2] + e) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+            *reinterpret_cast<float4*>(bufs.a[dst][3] + e) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+            *reinterpret_cast<float4*>(bufs.a[dst][4] + e) = make_float4(ot[0], ot[1], ot[2], ot[3]);
+        }
+        if (RECORD) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (k0 + m < cntS) ancOut[lo + s * kTile + k0 + m] = jg[s][m];
+        }
+        if (DEPOSIT) {
+            const double r = block_sum_quads<7>(acc, L.park);
+            if (tid < 7) tileSums[(size_t)d * kSumsPerTile + tid] = r;
+        } else if (POSE) {
+            double pacc[6] = { acc[0], acc[1], acc[2], acc[3], acc[4], acc[5] };
+            const double r = block_sum_quads<6>(pacc, L.park);
+            if (tid < 6) rsPart[(size_t)d * kRsPerTile + tid] = r;
+        }
+        }
     }
 }
 
@@ -1086,13 +1194,14 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample_dest(LocBufs bufs, Lo
                                                                const double* __restrict__ chunkBase,
                                                                const double* __restrict__ tileIncl, int* __restrict__ ancOut,
                                                                int numTiles, int n, RngKey key, RespawnShell sh,
-                                                               double* __restrict__ rsPart, const int* __restrict__ srcTileOf)
+                                                               double* __restrict__ rsPart, const DestPlan* __restrict__ plan)
 {
+    const DestPlan P = plan[blockIdx.x];    // read together with the control block: one round trip
     if (ctl->branch != 1) return;           // normalise-only step: nothing to do (wave-uniform exit)
     __shared__ DestLds L;
     if (POSE && blockIdx.x == 0 && threadIdx.x == 0) ctl->rsValid = 1;  // nobody in this launch reads it; k_loc_pose_tiles then exits
-    resample_dest_tile<false, false, RECORD, POSE>(bufs, ctl, chunkBase, tileIncl, numTiles, n, key, sh, key, Motion{}, Gate{},
-                                                   nullptr, ancOut, rsPart, srcTileOf, L);
+    resample_dest_tile<1, false, false, RECORD, POSE>(bufs, ctl, chunkBase, tileIncl, numTiles, n, key, sh, key, Motion{}, Gate{},
+                                                   nullptr, ancOut, rsPart, P, L);
 }
 
 // One deposit of an unsharded filter with deferred resampling, whichever way the previous decision went (it is
@@ -1100,24 +1209,36 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample_dest(LocBufs bufs, Lo
 // (workgroup d makes destination tile d), after a "normalise" decision this is k_loc_stream.  One launch instead of two
 // of which one would exit at once (an empty launch of 16 k workgroups plus its gap cost ~8 us of a 170 us deposit).
 // The two sides share the LDS.
-// Seven waves per SIMD (72 registers, no spill): the resampling side waits on dependent loads (source map -> weights
-// -> ancestors) before its arithmetic starts, and resident waves are what covers that (measured at N = 16 M:
-// 0.204 ms at 5 waves per SIMD, 0.190 at 6).
+// Seven waves per SIMD (71 registers, no spill).  What bounds the resampling side (measured at N = 16 M, round 2): its
+// arithmetic alone takes 0.095 ms (timing build without loads, selection and stores), its memory traffic alone ~0.115 ms,
+// and the two overlap only as far as OTHER resident waves are in their arithmetic while one waits -- a single wave
+// issues one vector instruction per ~9 cycles, so a SIMD needs five or six waves in arithmetic at once to be busy, of
+// eight it can hold.  Hence: as many waves as the registers allow (0.204 ms at 5 waves, 0.190 at 6, 0.175 at 7; two
+// destination tiles per workgroup, PF_DEPOSIT_TILES = 2, needs 85 registers and lost: 0.196), and arithmetic that
+// depends on nothing but the counter -- the unit normals of the thread's first two offspring -- drawn while the wave
+// waits for the source weights and for the ancestors (PF_NOISE_AHEAD1/2: 0.182 -> 0.163; a third offspring spills).
 template <bool MOTION>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_loc_deposit(LocBufs bufs, const LocCtl* __restrict__ ctl,
                                                          double* __restrict__ tileSums,
                                                          const double* __restrict__ chunkBase,
                                                          const double* __restrict__ tileIncl, int numTiles, int n,
                                                          RngKey keyRs, RespawnShell sh, RngKey key, Motion mo, Gate ga,
-                                                         const int* __restrict__ srcTileOf)
+                                                         const DestPlan* __restrict__ plan)
 {
     union DepositLds { DestLds dest; double red[7 * kThreads]; };
     __shared__ DepositLds L;
-    if (ctl->branch == 1)
-        resample_dest_tile<true, MOTION, false, false>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga, tileSums,
-                                                       nullptr, nullptr, srcTileOf, L.dest);
-    else
-        stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, 0, key, mo, ga, L.red);
+    const int d0 = blockIdx.x * kDepositTiles;
+    const DestPlan P = plan[d0];            // read together with the control block: one round trip (unused when streaming)
+    const int branch = ctl->branch;
+    if (branch == 1) {
+        resample_dest_tile<kDepositTiles, true, MOTION, false, false>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga,
+                                                                      tileSums, nullptr, nullptr, P, L.dest);
+    } else {
+        for (int s = 0; s < kDepositTiles && d0 + s < numTiles; ++s) {
+            if (s > 0) __syncthreads();     // the previous tile's last reads of L.red
+            stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, 0, key, mo, ga, L.red, d0 + s);
+        }
+    }
 }
 
 // The same for one shard of a sharded filter (global indices, foreign offspring staged).  The host launches it
@@ -1134,7 +1255,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_deposit_sharded(LocBufs bufs, 
     if (ctl->branch == 1)
         resample_deposit_tile<MOTION, true>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga, out, stage, L);
     else
-        stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, idx0, key, mo, ga, reinterpret_cast<double*>(&L));
+        stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, idx0, key, mo, ga, reinterpret_cast<double*>(&L), (int)blockIdx.x);
 }
 
 // Offspring received from the neighbouring shards: record k of `landing` belongs to local element k (k < lo: sent by
