@@ -422,13 +422,15 @@ __device__ __forceinline__ long long first_offspring_at(double b, double rStart,
 // What workgroup d of a destination-owned resampling needs before it can load anything else: the source tile t0 that
 // holds the ancestor of its first offspring, and the CDF values that bound tile t0 and its successors.  One 64-byte
 // record per destination tile, written by k_loc_decide_map: the workgroup reads it together with the control block
-// (one round trip) and then knows which weights to load; without it the tile bounds were two more dependent loads, and
-// a third for every further source tile.
-constexpr int kPlanEnds = 6;
+// (one round trip) and then knows which weights to load and which of its offspring each source tile takes; without it
+// the tile bounds were two more dependent loads (a third for every further source tile), and how far a tile gets was
+// worked out by every wave of every workgroup with float64 arithmetic.
+constexpr int kPlanEnds = 4;
 struct __attribute__((aligned(64))) DestPlan {
     int t0, pad;
     double start0;              // CDF value at the start of tile t0
     double end[kPlanEnds];      // CDF value at the end of tile t0 + i (the total weight from the last tile on)
+    int upto[kPlanEnds];        // first offspring (global index) whose position is not below end[i]: where tile t0 + i stops
 };
 static_assert(sizeof(DestPlan) == 64, "one cache line per destination tile");
 
@@ -495,6 +497,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_decide_map(LocCtl* __restrict_
     for (int i = 0; i < kPlanEnds; ++i) {
         const int e = t + i + 1;
         P.end[i] = tile_start_cdf(base, tileIncl, e < numTiles ? e : numTiles, 0.0, S);
+        P.upto[i] = (int)first_offspring_at(P.end[i], rStart, rStep, n);
     }
     plan[d] = P;
 }
@@ -1030,27 +1033,33 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
 #endif
     while (next < cnt) {                                    // uniform over the workgroup
         // The source tile of offspring `next`: the first tile from tPrev + 1 on whose end value exceeds its position (the
-        // last tile if there is none).  The record of this destination tile holds the end values of t0 .. t0 + 5, which is
-        // nearly always enough; beyond it the tile bounds are loaded, its successors probed 64 at a time.
-        const double un = rStart + rStep * (double)(lo + next);
-        int t = -1;
+        // last tile if there is none), and `upto`, how far that tile gets: the first offspring whose position is not
+        // below the tile's end value (u is non-decreasing in k).  The record of this destination tile answers both for
+        // the tiles t0 .. t0 + 3 with integer comparisons (tile t0 + i takes offspring `next` iff next < upto[i]); beyond
+        // them the tile bounds are loaded, successors probed 64 at a time, and upto found by arithmetic on 64 lanes.
+        int t = -1, upto = cnt;
         double tileStart = 0.0, tileEnd = 0.0;
 #pragma unroll
         for (int i = 0; i < kPlanEnds; ++i) {
             const int ti = P.t0 + i;
-            if (t < 0 && ti > tPrev && (ti >= numTiles - 1 || P.end[i] > un)) {
+            if (t < 0 && ti > tPrev && (ti >= numTiles - 1 || P.upto[i] > lo + next)) {
                 t = ti < numTiles - 1 ? ti : numTiles - 1;
                 tileStart = (i == 0) ? P.start0 : P.end[i - 1];
                 tileEnd = P.end[i];
+                const int rel = P.upto[i] - lo;
+                upto = (ti >= numTiles - 1 || rel > cnt) ? cnt : rel;
             }
         }
         if (t < 0) {
+            const double un = rStart + rStep * (double)(lo + next);
             const int a = (tPrev + 1 > P.t0 + kPlanEnds) ? tPrev + 1 : P.t0 + kPlanEnds;
             const int b = (a + 64 < numTiles) ? a + 64 : numTiles;
             t = wave_first_true(a, b, [&](int k) { return tile_start_cdf(chunkBase, tileIncl, k + 1, 0.0, S) > un; });
             if (t >= b) t = (b == numTiles) ? numTiles - 1 : find_source_tile(chunkBase, tileIncl, numChunks, numTiles, S, un);
             tileStart = tile_start_cdf(chunkBase, tileIncl, t, 0.0, S);
             tileEnd = tile_start_cdf(chunkBase, tileIncl, t + 1, 0.0, S);
+            upto = (t == numTiles - 1) ? cnt
+                                       : wave_first_true(next + 1, cnt, [&](int k) { return !(rStart + rStep * (double)(lo + k) < tileEnd); });
         }
         const bool lastTile = t == numTiles - 1;
         const float4 w4 = (t == tFirst) ? wFirst : (t == tAhead) ? wAhead : *reinterpret_cast<const float4*>(sw + (size_t)t * kTile + k0);
@@ -1058,9 +1067,6 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
             tAhead = t + 1;
             wAhead = *reinterpret_cast<const float4*>(sw + (size_t)tAhead * kTile + k0);
         }
-        // how far the tile gets: the first offspring whose position is not below its end value (u is non-decreasing in k;
-        // offspring `next` itself lies below it, that is how the tile was chosen).  Arithmetic only, no memory.
-        const int upto = lastTile ? cnt : wave_first_true(next + 1, cnt, [&](int k) { return !(rStart + rStep * (double)(lo + k) < tileEnd); });
         const int rem = n - t * kTile;
         const int nValid = rem < kTile ? rem : kTile;
         const float wq[4] = { w4.x, w4.y, w4.z, w4.w };
