@@ -15,7 +15,9 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <ctime>
+#include <limits>
 #include <mutex>
 #include <new>
 #include <unordered_set>
@@ -341,9 +343,30 @@ bool is_zero_motion(const float d[5])
 {   // exact zeros only: then x,y,z are unchanged bit for bit and theta only wraps (NaN compares false -> motion)
     return d[0] == 0.0f && d[1] == 0.0f && d[2] == 0.0f && d[3] == 0.0f && d[4] == 0.0f;
 }
+float float_of_bits(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
+
 Gate gate_of(float bx, float by, float bz, float range, float stdRange)
 {   // pfMeasurement.c:22,114,122
-    return Gate{ bx, by, bz, range, 3 * stdRange, (range < 3.0f) ? 0.1f : 0.5f };
+    const float inf = std::numeric_limits<float>::infinity();
+    Gate g{ bx, by, bz, range, 3 * stdRange, (range < 3.0f) ? 0.1f : 0.5f, 0.0f, inf };    // bounds: everything kept
+    const float r0 = g.range, t0 = g.thresh;
+    if (std::isnan(r0) || std::isnan(t0) || t0 == inf) return g;            // fabsf(..) > thresh is never true
+    if (t0 == -inf || r0 == -inf) { g.d2Lo = inf; g.d2Hi = -1.0f; return g; }   // always true: nothing kept (but NaN)
+    if (r0 == inf) { g.d2Lo = inf; g.d2Hi = inf; return g; }               // only sqrtf(inf) - inf = NaN is kept
+    // e(d2) = sqrtf(d2) - range (float) is non-decreasing in d2 >= 0; the gate keeps |e| <= thresh.  Non-negative floats
+    // are ordered like their bit patterns (0 .. 0x7F800000 = +inf): bisect for the first d2 with e >= -thresh and the
+    // first with e > thresh (both exist: e(+inf) = +inf).
+    const volatile float r = r0, t = t0;
+    auto e_of = [&](uint32_t bits) { const volatile float p = sqrtf(float_of_bits(bits)); const volatile float e = p - r; return (float)e; };
+    uint32_t lo = 0, hi = 0x7F800000u;
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (e_of(mid) >= -t) hi = mid; else lo = mid + 1; }
+    const uint32_t first = lo;
+    lo = 0; hi = 0x7F800000u;
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (e_of(mid) > t) hi = mid; else lo = mid + 1; }
+    const uint32_t past = lo;
+    if (first >= past) { g.d2Lo = inf; g.d2Hi = -1.0f; }                    // nothing is kept
+    else { g.d2Lo = float_of_bits(first); g.d2Hi = float_of_bits(past - 1); }
+    return g;
 }
 
 int read_ctl(pfx_loc* pf)
@@ -384,8 +407,8 @@ int alloc_device(pfx_loc* pf)
     const size_t slabBytes = pf->padded * 10 * sizeof(float);
     PF_HIP_OK(hipMalloc((void**)&pf->slab, slabBytes));
     PF_HIP_OK(hipMemsetAsync(pf->slab, 0, slabBytes, pf->stream));
-    for (int b = 0; b < 2; ++b)
-        for (int k = 0; k < 5; ++k) pf->bufs.a[b][k] = pf->slab + (size_t)(b * 5 + k) * pf->padded;
+    pf->bufs.slab = pf->slab;
+    pf->bufs.padded = pf->padded;
     const size_t nt = (size_t)pf->numTiles;
     PF_HIP_OK(hipMalloc((void**)&pf->tileSums, nt * kSumsPerTile * sizeof(double)));
     PF_HIP_OK(hipMalloc((void**)&pf->rsPart, nt * kRsPerTile * sizeof(double)));
@@ -643,7 +666,7 @@ extern "C" int pfx_loc_upload(pfx_loc* pf, const float* w, const float* x, const
     if (materialise(pf)) return -1;
     PF_HIP_OK(hipMemsetAsync(pf->slab, 0, pf->padded * 5 * sizeof(float), pf->stream));
     for (int k = 0; k < 5; ++k)
-        PF_HIP_OK(hipMemcpyAsync(pf->bufs.a[0][k], src[k], (size_t)n * sizeof(float), hipMemcpyHostToDevice, pf->stream));
+        PF_HIP_OK(hipMemcpyAsync(pf->bufs.p(0, k), src[k], (size_t)n * sizeof(float), hipMemcpyHostToDevice, pf->stream));
     if (launch_set_ctl(pf, 0, 0, 1.0f, 0)) return -1;
     // refresh the per-tile sums so that a pose query right after an upload is served
     float zero[5] = { 0, 0, 0, 0, 0 };
@@ -665,7 +688,7 @@ extern "C" int pfx_loc_download(pfx_loc* pf, float* w, float* x, float* y, float
     const int cur = pf->hostCtl->cur;
     float* dst[5] = { w, x, y, z, theta };
     for (int k = 0; k < 5; ++k)
-        if (dst[k]) PF_HIP_OK(hipMemcpyAsync(dst[k], pf->bufs.a[cur][k], (size_t)n * sizeof(float), hipMemcpyDeviceToHost, pf->stream));
+        if (dst[k]) PF_HIP_OK(hipMemcpyAsync(dst[k], pf->bufs.p(cur, k), (size_t)n * sizeof(float), hipMemcpyDeviceToHost, pf->stream));
     PF_HIP_OK(hipStreamSynchronize(pf->stream));
     if (w) {
         const float m = pf->hostCtl->wscale;        // pending w *= N/s of a normalise-only step (pfResample.c:80-82)
@@ -681,7 +704,7 @@ extern "C" int pfx_loc_device_arrays(pfx_loc* pf, void* d_ptrs[5], float* wscale
     DeviceGuard g(pf->device);
     if (materialise(pf)) return -1;
     if (read_ctl(pf)) return -1;
-    for (int k = 0; k < 5; ++k) d_ptrs[k] = pf->bufs.a[pf->hostCtl->cur][k];
+    for (int k = 0; k < 5; ++k) d_ptrs[k] = pf->bufs.p(pf->hostCtl->cur, k);
     if (wscale) *wscale = pf->hostCtl->wscale;
     return 0;
 }
@@ -1041,7 +1064,7 @@ extern "C" int pfx_loc_shard_ptrs_both(pfx_loc* pf, void** stage_send, void** st
     clear_error();
     *stage_send = pf->stageSlab ? (void*)pf->stageSlab : nullptr;
     *stage_land = pf->stageSlab ? (void*)landing_of(pf) : nullptr;
-    for (int k = 0; k < 5; ++k) { buf0[k] = pf->bufs.a[0][k]; buf1[k] = pf->bufs.a[1][k]; }
+    for (int k = 0; k < 5; ++k) { buf0[k] = pf->bufs.p(0, k); buf1[k] = pf->bufs.p(1, k); }
     return 0;
 }
 extern "C" int pfx_loc_shard_cur(const pfx_loc* pf) { return pf->shardCur; }

@@ -33,7 +33,13 @@ namespace pf {
 #ifndef PF_STREAM_UNROLL
 #define PF_STREAM_UNROLL 1
 #endif
-struct LocBufs { float* a[2][5]; };     // [ping-pong][w,x,y,z,theta], each padded to a whole tile
+// The ten particle arrays [ping-pong][w,x,y,z,theta], each padded to a whole tile, lie one after the other in one
+// allocation: base + stride instead of ten pointers keeps 16 scalar registers free in kernels that are short of them.
+struct LocBufs {
+    float* slab;
+    unsigned long long padded;
+    __host__ __device__ __forceinline__ float* p(int b, int k) const { return slab + (size_t)(b * 5 + k) * padded; }
+};
 
 struct LocCtl {
     int cur;            // buffer holding the current particles
@@ -68,7 +74,18 @@ struct ShardPlan {
 
 constexpr int kBranchLogSize = 65536;
 
-struct Gate { float bx, by, bz, range, thresh, minWeight; };
+// The range gate (pfMeasurement.c:118-123): a particle at squared distance d2 from the beacon keeps its weight unless
+// fabsf(sqrtf(d2) - range) > thresh.  sqrtf is correctly rounded and the subtraction monotone, so the particles that keep
+// their weight are exactly those with d2 in one closed interval of floats [d2Lo, d2Hi] (or d2 NaN), which the host finds
+// once per deposit by bisection over bit patterns with the reference's own expression (gate_of, pf_loc.hip): two
+// comparisons per particle on the device, no square root, the same decision for every float d2.
+struct Gate { float bx, by, bz, range, thresh, minWeight, d2Lo, d2Hi; };
+
+__device__ __forceinline__ bool gate_rejects(const Gate& ga, float dx, float dy, float dz)
+{
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    return d2 < ga.d2Lo || d2 > ga.d2Hi;            // NaN: kept, as in the reference
+}
 
 constexpr int kSumsPerTile = 8;     // s ss c sn wx wy wz (pad)
 constexpr int kRsPerTile = 8;       // x y z c sn count (pad)
@@ -88,11 +105,11 @@ __device__ __forceinline__ void stream_tile(const LocBufs& bufs, const LocCtl* _
     // Philox counter uses the global index, so the noise does not depend on how the filter is sharded
     const int cur = ctl->cur;
     const float wscale = ctl->wscale;
-    float* __restrict__ pw = bufs.a[cur][0];
-    float* __restrict__ px = bufs.a[cur][1];
-    float* __restrict__ py = bufs.a[cur][2];
-    float* __restrict__ pz = bufs.a[cur][3];
-    float* __restrict__ pt = bufs.a[cur][4];
+    float* __restrict__ pw = bufs.p(cur, 0);
+    float* __restrict__ px = bufs.p(cur, 1);
+    float* __restrict__ py = bufs.p(cur, 2);
+    float* __restrict__ pz = bufs.p(cur, 3);
+    float* __restrict__ pt = bufs.p(cur, 4);
 
     const long long base = (long long)tile * kTile + (long long)threadIdx.x * kPerThread;
     const float4 w4 = *reinterpret_cast<const float4*>(pw + base);
@@ -124,9 +141,7 @@ __device__ __forceinline__ void stream_tile(const LocBufs& bufs, const LocCtl* _
         th[k] = thi;
         if (GATE) {
             // pfMeasurement.c:118-123
-            const float dx = x[k] - ga.bx, dy = y[k] - ga.by, dz = z[k] - ga.bz;
-            const float pRange = sqrt_rn(dx * dx + dy * dy + dz * dz);
-            if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
+            if (gate_rejects(ga, x[k] - ga.bx, y[k] - ga.by, z[k] - ga.bz)) wi *= ga.minWeight;
         }
         w[k] = wi;
         // pfResample.c:44-48 and particleFilter.c:266-272: float products, added in double; the weight total is the
@@ -538,11 +553,11 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, LocCtl*
     const int src = ctl->src, dst = ctl->dst;
     const long long tbase = (long long)t * kTile;
     const long long e0 = tbase + tid * kPerThread;
-    const float4 w4 = *reinterpret_cast<const float4*>(bufs.a[src][0] + e0);
-    const float4 x4 = *reinterpret_cast<const float4*>(bufs.a[src][1] + e0);
-    const float4 y4 = *reinterpret_cast<const float4*>(bufs.a[src][2] + e0);
-    const float4 z4 = *reinterpret_cast<const float4*>(bufs.a[src][3] + e0);
-    const float4 t4 = *reinterpret_cast<const float4*>(bufs.a[src][4] + e0);
+    const float4 w4 = *reinterpret_cast<const float4*>(bufs.p(src, 0) + e0);
+    const float4 x4 = *reinterpret_cast<const float4*>(bufs.p(src, 1) + e0);
+    const float4 y4 = *reinterpret_cast<const float4*>(bufs.p(src, 2) + e0);
+    const float4 z4 = *reinterpret_cast<const float4*>(bufs.p(src, 3) + e0);
+    const float4 t4 = *reinterpret_cast<const float4*>(bufs.p(src, 4) + e0);
 
     const double rStart = ctl->rStart, rStep = ctl->rStep;
     const double shardBase = ctl->shardBase, shardEnd = ctl->shardEnd;
@@ -596,11 +611,11 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample(LocBufs bufs, LocCtl*
         // groups of four offspring aligned on the destination arrays: element (so + k) % 4 == 0 starts a group
         const int lead = (int)(((so % 4) + 4) % 4);         // elements of the first group that precede cb
         const int groups = (cnt + lead + 3) / 4;
-        float* __restrict__ dw = bufs.a[dst][0] + so;
-        float* __restrict__ dx = bufs.a[dst][1] + so;
-        float* __restrict__ dy = bufs.a[dst][2] + so;
-        float* __restrict__ dz = bufs.a[dst][3] + so;
-        float* __restrict__ dt = bufs.a[dst][4] + so;
+        float* __restrict__ dw = bufs.p(dst, 0) + so;
+        float* __restrict__ dx = bufs.p(dst, 1) + so;
+        float* __restrict__ dy = bufs.p(dst, 2) + so;
+        float* __restrict__ dz = bufs.p(dst, 3) + so;
+        float* __restrict__ dt = bufs.p(dst, 4) + so;
         int* __restrict__ da = RECORD ? ancOut + so : nullptr;
         const long long lo = cb - outBegin, hi = cb - aboveStart + below;
         const int fullB = kSelfB > 0 ? kSelfB : 0, fullE = kSelfE < cnt ? kSelfE : cnt;
@@ -714,11 +729,11 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
     const int src = ctl->src, dst = ctl->dst;
     const int tbase = t * kTile;
     const int e0 = tbase + tid * kPerThread;
-    const float4 w4 = *reinterpret_cast<const float4*>(bufs.a[src][0] + e0);
-    const float4 x4 = *reinterpret_cast<const float4*>(bufs.a[src][1] + e0);
-    const float4 y4 = *reinterpret_cast<const float4*>(bufs.a[src][2] + e0);
-    const float4 z4 = *reinterpret_cast<const float4*>(bufs.a[src][3] + e0);
-    const float4 t4 = *reinterpret_cast<const float4*>(bufs.a[src][4] + e0);
+    const float4 w4 = *reinterpret_cast<const float4*>(bufs.p(src, 0) + e0);
+    const float4 x4 = *reinterpret_cast<const float4*>(bufs.p(src, 1) + e0);
+    const float4 y4 = *reinterpret_cast<const float4*>(bufs.p(src, 2) + e0);
+    const float4 z4 = *reinterpret_cast<const float4*>(bufs.p(src, 3) + e0);
+    const float4 t4 = *reinterpret_cast<const float4*>(bufs.p(src, 4) + e0);
 
     const double rStart = ctl->rStart, rStep = ctl->rStep;
     const double shardBase = ctl->shardBase, shardEnd = ctl->shardEnd;     // [0, S) unless the filter is sharded
@@ -781,11 +796,11 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
     }
 
     const bool smallTurn = mo.stdTheta <= 1e-4f;
-    float* __restrict__ dw = bufs.a[dst][0];
-    float* __restrict__ dx = bufs.a[dst][1];
-    float* __restrict__ dy = bufs.a[dst][2];
-    float* __restrict__ dz = bufs.a[dst][3];
-    float* __restrict__ dt = bufs.a[dst][4];
+    float* __restrict__ dw = bufs.p(dst, 0);
+    float* __restrict__ dx = bufs.p(dst, 1);
+    float* __restrict__ dy = bufs.p(dst, 2);
+    float* __restrict__ dz = bufs.p(dst, 3);
+    float* __restrict__ dt = bufs.p(dst, 4);
 
     // thread k < 7 stores sum k of the piece (this source tile, destination tile d); thread 0 notes whether the
     // piece holds the tile's first / last offspring
@@ -841,9 +856,7 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
                     sincos_bounded(thi, sn, cs);
                 }
                 ot[m] = thi;
-                const float gx = ox[m] - ga.bx, gy = oy[m] - ga.by, gz = oz[m] - ga.bz;
-                const float pRange = sqrt_rn(gx * gx + gy * gy + gz * gz);
-                if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
+                if (gate_rejects(ga, ox[m] - ga.bx, oy[m] - ga.by, oz[m] - ga.bz)) wi *= ga.minWeight;
                 ow[m] = wi;
                 acc[0] += cdf_weight(wi);
                 acc[1] += wi * wi;
@@ -997,7 +1010,7 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
     // ancestors are being recorded (the reference selects one for them too, :70-72, before it overwrites them)
     int next = RECORD ? 0 : numSpawn - lo;
     next = next < 0 ? 0 : (next > cnt ? cnt : next);
-    const float* __restrict__ sw = bufs.a[src][0];
+    const float* __restrict__ sw = bufs.p(src, 0);
     // Every wavefront works the tile sequence out for itself (uniform values, loads that hit the same lines): nothing
     // but the CDF table goes through LDS, and its two barriers per tile are the only ones of the loop.
     int tPrev = P.t0 - 1, tAhead = -1;
@@ -1090,10 +1103,10 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
         // only after it has finished searching this one)
     }
 
-    const float* __restrict__ sx = bufs.a[src][1];
-    const float* __restrict__ sy = bufs.a[src][2];
-    const float* __restrict__ sz = bufs.a[src][3];
-    const float* __restrict__ st = bufs.a[src][4];
+    const float* __restrict__ sx = bufs.p(src, 1);
+    const float* __restrict__ sy = bufs.p(src, 2);
+    const float* __restrict__ sz = bufs.p(src, 3);
+    const float* __restrict__ st = bufs.p(src, 4);
     float ax[NSUB][4], ay[NSUB][4], az[NSUB][4], at[NSUB][4];
 #pragma unroll
     for (int s = 0; s < NSUB; ++s)
@@ -1149,9 +1162,7 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
                     sincos_bounded(thi, sn, cs);
                 }
                 ot[m] = thi;
-                const float gx = ox[m] - ga.bx, gy = oy[m] - ga.by, gz = oz[m] - ga.bz;
-                const float pRange = sqrt_rn(gx * gx + gy * gy + gz * gz);
-                if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
+                if (gate_rejects(ga, ox[m] - ga.bx, oy[m] - ga.by, oz[m] - ga.bz)) wi *= ga.minWeight;
                 acc[0] += cdf_weight(wi);
                 acc[1] += wi * wi;
                 acc[2] += wi * cs;
@@ -1171,11 +1182,11 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
         if (ow[0] + ox[1] + oy[2] + oz[3] + ot[0] == 12345.678f)
 #endif
         {
-            *reinterpret_cast<float4*>(bufs.a[dst][0] + e) = make_float4(ow[0], ow[1], ow[2], ow[3]);
-            *reinterpret_cast<float4*>(bufs.a[dst][1] + e) = make_float4(ox[0], ox[1], ox[2], ox[3]);
-            *reinterpret_cast<float4*>(bufs.a[dst][2] + e) = make_float4(oy[0], oy[1], oy[2], oy[3]);
-            *reinterpret_cast<float4*>(bufs.a[dst][3] + e) = make_float4(oz[0], oz[1], oz[2], oz[3]);
-            *reinterpret_cast<float4*>(bufs.a[dst][4] + e) = make_float4(ot[0], ot[1], ot[2], ot[3]);
+            *reinterpret_cast<float4*>(bufs.p(dst, 0) + e) = make_float4(ow[0], ow[1], ow[2], ow[3]);
+            *reinterpret_cast<float4*>(bufs.p(dst, 1) + e) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+            *reinterpret_cast<float4*>(bufs.p(dst, 2) + e) = make_float4(oy[0], oy[1], oy[2], oy[3]);
+            *reinterpret_cast<float4*>(bufs.p(dst, 3) + e) = make_float4(oz[0], oz[1], oz[2], oz[3]);
+            *reinterpret_cast<float4*>(bufs.p(dst, 4) + e) = make_float4(ot[0], ot[1], ot[2], ot[3]);
         }
         if (RECORD) {
 #pragma unroll
@@ -1279,11 +1290,11 @@ __global__ __launch_bounds__(kThreads) void k_loc_land(LocBufs bufs, const LocCt
     __shared__ double red[DEPOSIT ? 7 * kThreads : 1];
     const int tile = (int)blockIdx.x < tilesBelow ? (int)blockIdx.x : firstTileAbove + ((int)blockIdx.x - tilesBelow);
     const int cur = ctl->cur;
-    float* __restrict__ pw = bufs.a[cur][0];
-    float* __restrict__ px = bufs.a[cur][1];
-    float* __restrict__ py = bufs.a[cur][2];
-    float* __restrict__ pz = bufs.a[cur][3];
-    float* __restrict__ pt = bufs.a[cur][4];
+    float* __restrict__ pw = bufs.p(cur, 0);
+    float* __restrict__ px = bufs.p(cur, 1);
+    float* __restrict__ py = bufs.p(cur, 2);
+    float* __restrict__ pz = bufs.p(cur, 3);
+    float* __restrict__ pt = bufs.p(cur, 4);
     const bool smallTurn = mo.stdTheta <= 1e-4f;
     double acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
@@ -1300,9 +1311,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_land(LocBufs bufs, const LocCt
                 th = wrap_two_pi(th);
                 sincos_bounded(th, sn, cs);
             }
-            const float gx = x - ga.bx, gy = y - ga.by, gz = z - ga.bz;
-            const float pRange = sqrt_rn(gx * gx + gy * gy + gz * gz);
-            if (fabsf(pRange - ga.range) > ga.thresh) wi *= ga.minWeight;
+            if (gate_rejects(ga, x - ga.bx, y - ga.by, z - ga.bz)) wi *= ga.minWeight;
             acc[0] += cdf_weight(wi);
             acc[1] += wi * wi;
             acc[2] += wi * cs;
@@ -1364,7 +1373,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_pose_tiles(LocBufs bufs, const
     if (ctl->branch != 1 || ctl->rsValid) return;
     __shared__ double red[6 * kThreads];
     const int cur = ctl->cur;
-    pose_tile_body<true>(bufs.a[cur][0], bufs.a[cur][1], bufs.a[cur][2], bufs.a[cur][3], bufs.a[cur][4], ctl->wscale, n, rsPart, red);
+    pose_tile_body<true>(bufs.p(cur, 0), bufs.p(cur, 1), bufs.p(cur, 2), bufs.p(cur, 3), bufs.p(cur, 4), ctl->wscale, n, rsPart, red);
 }
 
 // The same pass over a CALLER's device arrays, partials into a workspace the caller of the kernel names
@@ -1385,11 +1394,11 @@ __global__ __launch_bounds__(kThreads) void k_loc_spawn(LocBufs bufs, LocCtl* __
 {
     __shared__ double red[6 * kThreads];
     const int cur = ctl->cur;
-    float* __restrict__ pw = bufs.a[cur][0];
-    float* __restrict__ px = bufs.a[cur][1];
-    float* __restrict__ py = bufs.a[cur][2];
-    float* __restrict__ pz = bufs.a[cur][3];
-    float* __restrict__ pt = bufs.a[cur][4];
+    float* __restrict__ pw = bufs.p(cur, 0);
+    float* __restrict__ px = bufs.p(cur, 1);
+    float* __restrict__ py = bufs.p(cur, 2);
+    float* __restrict__ pz = bufs.p(cur, 3);
+    float* __restrict__ pt = bufs.p(cur, 4);
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
     const long long tbase = (long long)blockIdx.x * kTile;
 #pragma unroll

@@ -87,6 +87,48 @@ def test_apply_range_bit_exact(pfm, ora, case, n):
     assert 0 < int(np.sum(gw != p[:, 0])) < n                                 # the gate did discriminate
 
 
+@pytest.mark.parametrize("gate", [(4.0, 0.1), (2.5, 0.5), (0.2, 0.1), (7.3, 0.033), (1.5, 0.5), (3.0, 0.0), (0.0, 0.0),
+                                  (1e-20, 1e-21), (5.0, float("inf")), (5.0, float("nan")), (float("inf"), 0.1), (5.0, -0.1)],
+                         ids=lambda g: f"r{g[0]}s{g[1]}")
+def test_range_gate_at_its_boundaries(pfm, ora, gate):
+    """The kernels decide the gate from the squared distance against two bounds the host derives from the reference's
+    expression fabsf(sqrtf(d2) - range) > 3 sigma (pfMeasurement.c:118-123): particles whose distance walks float by float
+    across both edges of the shell (and 0, denormal, huge and NaN positions) must get the oracle's weight, bit for bit."""
+    rng_, std = gate
+    n = 4096
+    g, o = _pair(pfm, ora, n)
+    p = np.zeros((n, 5), dtype=np.float32)
+    p[:, 0] = 1.0
+    r, t = np.float32(rng_), np.float32(3.0) * np.float32(std)
+    edges = [e for e in (r - t, r + t) if np.isfinite(e) and e >= 0]
+    d = []
+    for e in edges:
+        v = np.float32(e)
+        lo = v
+        for _ in range(300):
+            lo = np.nextafter(lo, np.float32(-np.inf))
+        w = [lo]
+        for _ in range(600):
+            w.append(np.nextafter(w[-1], np.float32(np.inf)))
+        d += w
+    d += [0.0, 1e-30, 1e-22, 1e-19, 3e18, 1e19, 1e30, np.inf, np.nan]
+    d = np.abs(np.array(d, dtype=np.float32))
+    k = min(len(d), n // 3)
+    bx, by, bz = 0.0, 0.0, 0.0
+    p[:k, 1] = d[:k]                          # along x: d2 = x * x
+    p[k:2 * k, 2] = -d[:k]                    # along -y
+    h = (d[:k] * np.float32(0.70710678)).astype(np.float32)
+    p[2 * k:3 * k, 1] = h                     # on the diagonal: d2 = h * h + h * h
+    p[2 * k:3 * k, 3] = h
+    _load(g, o, p)
+    g.apply_range(bx, by, bz, float(rng_), float(std))
+    o.apply_range(bx, by, bz, float(rng_), float(std))
+    gw, ow = g.download()[0], o.arrays()[0]
+    assert np.array_equal(gw, ow)
+    if np.isfinite(rng_) and np.isfinite(std) and std >= 0 and rng_ > 1e-10:
+        assert 0 < int(np.sum(gw[:3 * k] != 1.0)) < 3 * k          # both outcomes occurred
+
+
 def test_apply_range_idempotent_when_nothing_gated(pfm, ora):
     n = 5000
     g, o = _pair(pfm, ora, n)
