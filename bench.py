@@ -17,11 +17,13 @@ case, not a tracking demo.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--particles PER_GPU] [--force-branch -1|0|1]
 
-Before the W warm-up steps the filter always runs PRE_ROLL untimed steps: the first steps after the spawn work on
-a cloud that is still collapsing from the initial range shell (larger respawn share, clustered weights; the
-resampling launch measured 0.24-0.27 ms there against 0.18-0.20 ms once the filter tracks) -- the state of
-the workload, not of the clock -- and a short run would otherwise time that transient instead of the filter
-at work.
+Before the W warm-up steps the filter always runs PRE_ROLL = 400 untimed steps (0.1 s at N = 16 M): for the first
+~300 steps after the spawn the cloud is still collapsing from the initial range shell (larger respawn share, clustered
+weights, more source tiles per destination tile; the resampling launch takes 0.17 ms there against 0.15 ms once the
+filter tracks) -- the state of the workload, not of the clock -- and a 20-step run would otherwise time that
+transient while a 200-step run averages over its end: 115 vs 126 G particle-updates/s with a 40-step pre-roll,
+133 vs 131 with 400.  The transient is still in the record: `extra.transient` is the same measurement behind a
+40-step pre-roll.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): ONE filter of N x 16 M particles sharded by
 particle range; per deposit an all-gather of the per-GPU weight/pose sums (RCCL) gives every rank the
@@ -45,15 +47,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# SURVEY.md 8d / BASELINE.md: algorithmic (compulsory) HBM bytes per particle, SoA f32.  The fused kernel does the
-# work of the resample (40) AND of the following deposit's streaming pass (44 with motion / 28 without) in one launch;
-# what it really moves is in "traffic" (rocprofv3 PMC, profiles/pmc_traffic.json).
-ALG_BYTES = {"stream": 44, "stream_static": 28, "resample": 40, "resample_stream": 84, "resample_static": 68}
+# SURVEY.md 8d / BASELINE.md: algorithmic (compulsory) HBM bytes per particle, SoA f32: a deposit's streaming pass 44
+# (with motion) / 28 (without), a resampling 40 (source weights + ancestors read, offspring written).  The fused kernel
+# does a resampling AND the following deposit in one launch; the offspring never leave the registers in between, so
+# what such a launch MUST move is the resampling's 40 B and the roofline prices it at that.  (Priced as the two reference
+# passes it replaces, ROWS_REPLACED, it would come out above the HBM peak: 84 B x 16 M / 0.155 ms = 8.7 TB/s.)  What it
+# really moves is in "traffic" (rocprofv3 PMC, profiles/pmc_traffic.json).
+ALG_BYTES = {"stream": 44, "stream_static": 28, "resample": 40, "resample_stream": 40, "resample_static": 40}
+ROWS_REPLACED = {"resample_stream": 84, "resample_static": 68}
 KERNEL_OF = {"stream": "k_loc_stream<motion,gate>", "stream_static": "k_loc_stream<gate>", "resample": "k_loc_resample_dest",
              "resample_stream": "k_loc_deposit<motion> (resampling side)", "resample_static": "k_loc_deposit<static> (resampling side)"}
 # (a sharded filter runs the same two sides in k_loc_deposit_sharded)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
-PRE_ROLL = 40               # untimed steps before the warm-up (see the module docstring)
+PRE_ROLL = int(os.environ.get("BENCH_PRE_ROLL", "400"))     # untimed steps before the warm-up (see the module docstring)
 
 
 def scene(n_steps):
@@ -321,8 +327,10 @@ def measure_slam(F, B, K, W, world, rank, local, dist, torch, with_cpu=False, ce
 
 
 # ------------------------------------------------------------------ config 3: one Loc filter
-def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, headline):
-    """PRE_ROLL + W untimed steps, K timed; returns (record fields, per-kernel table) on rank 0, (None, None) elsewhere"""
+def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, headline, pre_roll=None):
+    """pre_roll (default PRE_ROLL) + W untimed steps, K timed; returns (record fields, per-kernel table) on rank 0,
+    (None, None) elsewhere"""
+    PRE_ROLL = globals()["PRE_ROLL"] if pre_roll is None else pre_roll
     pg = os.environ.get("BENCH_PG", "nccl")
     bx, truth, rng = scene(PRE_ROLL + K + W + 1)
     force_sharded = os.environ.get("BENCH_FORCE_SHARDED") == "1"      # rehearsal: the sharded host logic on one rank
@@ -409,6 +417,9 @@ def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, head
             gbs = ALG_BYTES[nm] * n / (avg_ms * 1e-3) / 1e9
             per[nm] = {"launches": int(sel.shape[0]), "avg_ms": avg_ms, "alg_bytes_per_particle": ALG_BYTES[nm],
                        "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS, "total_ms": float(sel.sum())}
+            if nm in ROWS_REPLACED:         # the same launch priced as the reference passes it stands for
+                per[nm]["reference_passes_bytes_per_particle"] = ROWS_REPLACED[nm]
+                per[nm]["reference_passes_GBs"] = ROWS_REPLACED[nm] * n / (avg_ms * 1e-3) / 1e9
     return rec, per
 
 
@@ -511,24 +522,39 @@ def main():
             if traffic:
                 roof["dram_GBs"] = traffic / (d["avg_ms"] * 1e-3) / 1e9      # what the kernel really moves per second
             if dominant.startswith("resample_"):
-                roof["note"] = ("one launch does the reference's resample (40 algorithmic B/particle) and the next deposit's "
-                                "streaming pass (44 / 28); `traffic` is what it really moves.  This side of the kernel is "
-                                "limited by vector-ALU issue (two Philox blocks, four Box-Muller pairs per offspring) and by the "
-                                "dependent loads in front of it (source map -> weights -> ancestors), not by HBM")
+                roof["reference_passes_bytes_per_particle"] = d["reference_passes_bytes_per_particle"]
+                roof["reference_passes_GBs"] = d["reference_passes_GBs"]
+                roof["note"] = ("one launch does the reference's resample AND the next deposit's streaming pass; the offspring "
+                                "stay in registers in between, so the launch is priced at the 40 B/particle it must move "
+                                "(rounds before 2k priced it at the 84 B of the two passes it replaces: reference_passes_GBs, "
+                                "above the HBM peak by now); `traffic` / dram_GBs is what it really moves.  Bound by how much of "
+                                "its arithmetic (two Philox blocks, four Box-Muller pairs per offspring) the resident waves can "
+                                "overlap with the dependent loads record -> weights -> ancestors, DESIGN.md 4.2")
         extra = None
         if world == 1 and not args.no_extras and not force_sharded:
             extra = {"note": f"same scene and step as the headline, {PRE_ROLL} pre-roll + 10 warm-up steps, no per-kernel events",
-                     "n_sweep": [], "always_resample": None, "config5": None}
+                     "n_sweep": [], "always_resample": None, "transient": None, "config5": None}
             for nn, kk in ((1000000, 100), (1 << 24, 50), (1 << 26, 30)):
                 r, _ = measure_loc(pfm, torch, dist, 1, 0, local, nn, kk, 10, -1, args, headline=False)
                 extra["n_sweep"].append(r)
             r, _ = measure_loc(pfm, torch, dist, 1, 0, local, n, 50, 10, 1, args, headline=False)
             r["force_branch"] = 1
             extra["always_resample"] = r
+            r, _ = measure_loc(pfm, torch, dist, 1, 0, local, n, 20, 5, -1, args, headline=False, pre_roll=40)
+            r["pre_roll_steps"] = 40
+            extra["transient"] = r
             extra["config5"] = measure_slam(512, 4, 60, 10, 1, 0, local, dist, torch, with_cpu=not args.no_cpu_baseline)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
+        # the whole step against the roofline, priced as the reference's passes: one deposit with motion, one
+        # without, and the resamplings the decisions called for
+        step_bytes = 44 + 28 + 40 * 2 * (rec["resample_fraction"] or 0.0)
+        step_gbs = step_bytes * n * world / (rec["ms_per_step"] * 1e-3) / 1e9
+        step_roof = {"alg_bytes_per_particle_step": step_bytes, "achieved": step_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                     "frac": step_gbs / (HBM_PEAK_GBS * world),
+                     "note": "depositRange (44 B/particle) + depositRssi (28) + resample_fraction x 2 resamplings (40 each), "
+                             "over ms_per_step: launch gaps, the two small kernels per deposit and fusion gains all included"}
         out = {
             "metric": "particle-updates/sec (range update+resample) at N=16M",
             "value": rec["value"], "unit": "particle-updates/s",
@@ -548,7 +574,7 @@ def main():
                        "scene_note": "SURVEY's config-3 scene is self-contradictory on purpose of traffic: every depositRssi asserts "
                                      "1.5 +- 1.5 m to a beacon >= 5 m from the truth, so each one gates the whole cloud and forces "
                                      "the 5 % respawn; the estimate sits ~1 m off the truth and half the deposits resample"},
-            "roofline": roof, "kernels": per, "cpu_baseline": cpu, "extra": extra,
+            "roofline": roof, "step_roofline": step_roof, "kernels": per, "cpu_baseline": cpu, "extra": extra,
         }
         emit(out)
     if world > 1 or force_sharded:
