@@ -465,6 +465,62 @@ def test_deferred_resampling_concentrated_weight(pfm, n):
         assert np.array_equal(u, v), f"array {c}"
 
 
+def _ragged_weights(n):
+    """weights that make the source tiles of a destination tile as irregular as they get: runs of zero-weight tiles (to be
+    skipped), runs of tiles of tiny weights (a destination tile then draws from dozens of source tiles: far beyond the
+    four tiles its plan record describes), single heavy particles (one source tile feeds many destination tiles), and
+    ordinary stretches in between"""
+    w = np.full(n, 0.05, dtype=np.float32)
+    t = 1024
+    w[3 * t: 9 * t] = 0.0                                       # six empty tiles in a row
+    w[9 * t + 17] = 300.0                                       # ... then one particle worth ~6 destination tiles
+    w[20 * t: 70 * t] = np.float32(3 * 2.0 ** -20)              # 50 tiles worth 0.15 offspring each
+    w[70 * t: 70 * t + 5] = [1.0, 0.0, 2.5, 0.0, 1.0]
+    w[90 * t: 130 * t: 7] = 0.0
+    w[150 * t:] = np.where(_synth.u01(9, n - 150 * t) < 0.02, 1.0, 0.0).astype(np.float32)
+    w[-1] = 40.0
+    return w
+
+
+def test_resample_ragged_source_tiles(pfm, ora):
+    """ancestor for ancestor against the oracle (recorded: k_loc_resample_dest), then the production kernels on the same
+    weights: undeferred (k_loc_resample_dest) and deferred (the resampling fused into the next deposit by k_loc_deposit)
+    must leave bit-identical particles."""
+    n = 200 * 1024 + 333
+    w = _ragged_weights(n)
+    rs = np.random.RandomState(12)
+    x, y, z = (rs.uniform(-3, 3, n).astype(np.float32) for _ in range(3))
+    th = rs.uniform(0, 6.28, n).astype(np.float32)
+    g, o = _pair(pfm, ora, n)
+    _load(g, o, np.stack([w, x, y, z, th], axis=1), epoch=5)
+    g.record_ancestors(True)
+    g.resample(0.0, 0.0, 0.0, 10.0, 0.1)                        # ESS ~ 300 of 200 000: both sides resample
+    o.resample(0.0, 0.0, 0.0, 10.0, 0.1)
+    gs, os_ = g.last_stats(), o.last_stats()
+    assert int(gs["branch"]) == 1 and int(os_["branch"]) == 1
+    assert gs["S"] == os_["S"] and gs["rStart"] == os_["rStart"] and gs["rStep"] == os_["rStep"]
+    anc = g.last_ancestors()
+    assert np.array_equal(anc, o.last_ancestors())
+    assert np.all(w[anc[int(gs["numSpawn"]):]] > 0)             # nobody descends from a weightless particle
+    per_dest = [np.unique(anc[d * 1024:(d + 1) * 1024] // 1024).size for d in range(n // 1024)]
+    assert max(per_dest) > 4, "one destination tile should draw from more source tiles than its plan record holds (4)"
+    fs = []
+    for deferred in (True, False):
+        f = pfm.DeviceParticleFilterLoc(n, seed=77)
+        f.set_deferred(deferred)
+        f.upload(w, x, y, z, th)
+        f.epoch = 3
+        f.set_force_branch(1)
+        f.depositVio(1.0, 0.0, 0.0, 0.0, 0.0)
+        f.depositRange(0.5, 0.2, 0.1, 3.0, 0.2)
+        f.depositVio(1.2, 0.1, -0.05, 0.02, 0.0)
+        f.depositRange(-1.0, 0.7, 0.0, 2.5, 0.1)                # fused with the resampling above
+        f.depositRssi(0.3, 0.3, 0.0, -60)                       # ... and again, without motion
+        fs.append(f)
+    for c, (u, v) in enumerate(zip(fs[0].download(), fs[1].download())):
+        assert np.array_equal(u, v), f"array {c}"
+
+
 @pytest.mark.parametrize("n", [10000, 50021])
 def test_deferred_sequence_tracks_oracle(pfm, ora, n):
     """The oracle comparison of test_deposit_sequence_tracks_oracle with the GPU pose read only every fifth
