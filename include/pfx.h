@@ -237,7 +237,10 @@ int      pfx_slam_device_arrays(pfx_slam* pf, void* d_tag[5], void* d_bcn[5], vo
 /* binding between the reference-layout structs and device filters */
 pfx_slam* pfx_slam_of(const particleFilterSlam_t* pf);                       /* NULL if the struct is not bound */
 int      pfx_slam_slot_of(const particleFilterSlam_t* pf, const bcn_t* bcn); /* -1 until the beacon's first deposit */
-int      pfx_slam_sync_host(particleFilterSlam_t* pf, bcn_t* bcn);           /* fill pTag[] and (bcn != NULL) pBcn[][] from HBM */
+/* fill pTag[] and (bcn != NULL) pBcn[][] from HBM.  Until their next state-changing call the structs are then complete
+ * checkpoints: their bytes may be stored, copied or moved and are continued from where they are found (the reference's
+ * structs are PODs); a copy taken without this call is refused at its first use with a message. */
+int      pfx_slam_sync_host(particleFilterSlam_t* pf, bcn_t* bcn);
 void     pfx_slam_release(particleFilterSlam_t* pf);                         /* free the device side */
 
 /* ---- binding between the reference-layout structs and device filters ---- */

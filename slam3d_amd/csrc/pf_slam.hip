@@ -18,6 +18,7 @@
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
+#include <unistd.h>
 
 using namespace pf;
 
@@ -113,6 +114,10 @@ struct pfx_slam {
     // reference-layout API: slot of every bcn_t this filter has met, by struct address.  particleFilterSlam_addBcn
     // (the reference's way of resetting a beacon) wipes the struct's own binding record; the address finds the slot again.
     std::unordered_map<uintptr_t, int> legacySlots;
+    // ... and how many state-changing calls the tag particles / each beacon slot have seen through that API: a struct
+    // whose binding record shows another count holds a copy of an earlier state (see "POD copies" below)
+    unsigned long long legacyOps = 0;
+    unsigned long long bcnOps[kSlamMaxBcns] = {};
 };
 
 static std::mutex g_smu;
@@ -676,26 +681,97 @@ namespace {
 
 // Binding records kept in the first bytes of the structs' scratch arrays (pTagBuf / pBcnBuf: resampling
 // scratch in the reference, pfResample.c:119-120, 182-188).
-struct SlamStash { uint64_t magic; uint64_t self; pfx_slam* handle; };
-struct BcnStash { uint64_t magic; uint64_t self; pfx_slam* owner; int64_t slot; };
+//
+// POD copies (the reference's structs ARE the filter).  Both records count the state-changing calls
+// their struct has been through (`ops`, mirrored by the device filter) and remember the count at which
+// pfx_slam_sync_host last filled the struct's particle array (`syncedOps`).  A struct met at an address, or with a count,
+// other than the device filter knows -- a copy, a checkpoint read back, bytes copied back over the live struct -- is
+// continued from its own pTag[] / pBcn[][] if that array is current (syncedOps == ops), and refused with a message if it
+// is not.  (No device-side clone here as particleFilterLoc_t copies get: a SLAM filter with its beacons is gigabytes.)
+// A restored tag filter draws new noise streams for its beacons if they land in other slots than before.
+struct SlamStash { uint64_t magic; uint64_t self; pfx_slam* handle; uint64_t process; unsigned long long ops, syncedOps; uint32_t seed, epoch; };
+struct BcnStash { uint64_t magic; uint64_t self; pfx_slam* owner; int64_t slot; uint64_t process; unsigned long long ops, syncedOps; };
+constexpr unsigned long long kNeverSynced = ~0ull;
+const uint64_t g_slamProcess = (uint64_t)time(nullptr) * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)&g_slive ^ ((uint64_t)getpid() << 32);
 constexpr uint64_t kSlamMagic = 0x7066536C6D484950ull;   // "pfSlmHIP"
 constexpr uint64_t kBcnMagic = 0x706642636E484950ull;    // "pfBcnHIP"
 
 SlamStash* stash_of(const particleFilterSlam_t* pf) { return reinterpret_cast<SlamStash*>(const_cast<tagParticle_t*>(pf->pTagBuf)); }
 BcnStash* stash_of(const bcn_t* b) { return reinterpret_cast<BcnStash*>(const_cast<bcnParticle_t*>(b->pBcnBuf)); }
 
+bool slam_live(pfx_slam* h, uint64_t process)
+{
+    if (process != g_slamProcess) return false;
+    std::lock_guard<std::mutex> lk(g_smu);
+    return g_slive.count(h) != 0;
+}
+
+// strictly this struct, at this address, bound to a live filter (whatever its contents' age)
 pfx_slam* bound(const particleFilterSlam_t* pf)
 {
     const SlamStash* s = stash_of(pf);
     if (s->magic != kSlamMagic || s->self != (uint64_t)(uintptr_t)pf) return nullptr;
-    std::lock_guard<std::mutex> lk(g_smu);
-    return g_slive.count(s->handle) ? s->handle : nullptr;
+    return slam_live(s->handle, s->process) ? s->handle : nullptr;
 }
 
-pfx_slam* must_be_bound(const particleFilterSlam_t* pf, const char* fn)
+int legacy_n(const char* env, int dflt);
+int legacy_device();
+template <typename P> void aos_to_soa(const P* p, size_t n, std::vector<float>& out);
+
+void bind_slam(particleFilterSlam_t* pf, pfx_slam* h)
 {
-    pfx_slam* h = bound(pf);
-    if (!h) { set_error("%s: struct %p was not initialised with particleFilterSlam_init (or was moved)", fn, (const void*)pf); fail(fn); }
+    SlamStash* s = stash_of(pf);
+    s->magic = kSlamMagic; s->self = (uint64_t)(uintptr_t)pf; s->handle = h; s->process = g_slamProcess;
+    s->ops = h->legacyOps; s->syncedOps = kNeverSynced;
+    s->seed = h->fl[0].seed; s->epoch = h->fl[0].epoch;
+}
+
+void note_slam_state(particleFilterSlam_t* pf, pfx_slam* h)
+{   // after a state-changing call
+    SlamStash* s = stash_of(pf);
+    s->ops = ++h->legacyOps; s->seed = h->fl[0].seed; s->epoch = h->fl[0].epoch;
+}
+
+// the device filter behind `pf`; a struct that is a copy of an earlier state is first continued from its own pTag[]
+pfx_slam* must_be_bound(const particleFilterSlam_t* cpf, const char* fn)
+{
+    particleFilterSlam_t* pf = const_cast<particleFilterSlam_t*>(cpf);
+    SlamStash* s = stash_of(pf);
+    if (s->magic != kSlamMagic) {
+        set_error("%s: struct %p was not initialised with particleFilterSlam_init", fn, (const void*)pf);
+        fail(fn);
+        return nullptr;
+    }
+    const bool live = slam_live(s->handle, s->process);
+    const bool here = s->self == (uint64_t)(uintptr_t)pf;
+    if (live && here && s->ops == s->handle->legacyOps) return s->handle;       // the common case
+    const SlamStash was = *s;
+    if (was.syncedOps != was.ops) {
+        set_error("%s: struct %p is a copy of a filter that has since moved on (or is gone, or was moved) and does not hold "
+                  "its particles: call pfx_slam_sync_host() before copying a struct that is to be continued", fn, (const void*)pf);
+        fail(fn);
+        return nullptr;
+    }
+    pfx_slam* h = (live && here) ? was.handle
+                                 : pfx_slam_create(1, PF_N_TAG_SLAM, PF_N_BCN, kSlamMaxBcns, nullptr, was.seed, legacy_device());
+    if (!h) { fail(fn); return nullptr; }
+    if (h->D.nTag != PF_N_TAG_SLAM || h->D.nBcn != PF_N_BCN) {
+        set_error("%s: a stored struct cannot be continued while the particle counts are overridden", fn);
+        fail(fn);
+        return nullptr;
+    }
+    std::vector<float> tmp;
+    const size_t n = PF_N_TAG_SLAM;
+    aos_to_soa(&pf->pTag[0], n, tmp);
+    if (pfx_slam_upload_tag(h, 0, &tmp[0], &tmp[n], &tmp[2 * n], &tmp[3 * n], &tmp[4 * n])) {
+        if (!(live && here)) pfx_slam_destroy(h);
+        fail(fn);
+        return nullptr;
+    }
+    h->fl[0].seed = was.seed; h->fl[0].epoch = was.epoch;
+    ++h->legacyOps;
+    bind_slam(pf, h);
+    stash_of(pf)->syncedOps = h->legacyOps;         // pTag[] is what the filter holds
     return h;
 }
 
@@ -740,11 +816,23 @@ void aos_to_soa(const P* p, size_t n, std::vector<float>& out)
 int slot_of(pfx_slam* h, bcn_t* b, const char* fn)
 {
     BcnStash* s = stash_of(b);
-    if (s->magic == kBcnMagic && s->self == (uint64_t)(uintptr_t)b && s->owner == h && s->slot >= 0 && s->slot < h->fl[0].numBcns)
-        return (int)s->slot;
+    const bool mine = s->magic == kBcnMagic && s->self == (uint64_t)(uintptr_t)b && s->owner == h && s->process == g_slamProcess &&
+                      s->slot >= 0 && s->slot < h->fl[0].numBcns;
+    if (mine && s->ops == h->bcnOps[s->slot]) return (int)s->slot;
+    // Not this filter's beacon as it last saw it.  A struct that carries a record of this library (a copy, a checkpoint
+    // read back, bytes copied back over the live struct) must hold its particles to be continued; one without a record
+    // (filled by the reference library, or reset with particleFilterSlam_addBcn) is taken at its word.
+    if (s->magic == kBcnMagic && b->initialized && s->syncedOps != s->ops) {
+        set_error("%s: beacon %p is a copy of a beacon that has since moved on (or belongs to a filter that is gone) and does "
+                  "not hold its particles: call pfx_slam_sync_host(pf, bcn) before copying a beacon that is to be continued",
+                  fn, (const void*)b);
+        return -1;
+    }
     int slot;
     const auto it = h->legacySlots.find((uintptr_t)b);
-    if (it != h->legacySlots.end()) {
+    if (mine) {
+        slot = (int)s->slot;                // rolled back in place: its rows are replaced below
+    } else if (it != h->legacySlots.end()) {
         slot = it->second;                  // reset with particleFilterSlam_addBcn: same struct, same slot, spawned afresh
     } else {
         slot = pfx_slam_add_bcn(h, 0);
@@ -765,7 +853,9 @@ int slot_of(pfx_slam* h, bcn_t* b, const char* fn)
         // binding record first: pBcnBuf, where it lives, is not part of the state
         if (pfx_slam_upload_bcn(h, 0, slot, &tmp[0], &tmp[n], &tmp[2 * n], &tmp[3 * n], &tmp[4 * n], 1)) return -1;
     }
-    s->magic = kBcnMagic; s->self = (uint64_t)(uintptr_t)b; s->owner = h; s->slot = slot;
+    s->magic = kBcnMagic; s->self = (uint64_t)(uintptr_t)b; s->owner = h; s->slot = slot; s->process = g_slamProcess;
+    s->ops = ++h->bcnOps[slot];
+    s->syncedOps = b->initialized ? s->ops : kNeverSynced;      // uploaded from pBcn[][]: the struct holds what the device holds
     return slot;
 }
 
@@ -813,6 +903,11 @@ void legacy_deposit(particleFilterSlam_t* pf, bcn_t* bcn, float range, float std
     h->fl[0].bcnInit[r.target] = bcn->initialized != 0;
     if (slam_step(h, &r, 1)) { fail(fn); return; }
     bcn->initialized = 1;
+    note_slam_state(pf, h);
+    for (int i = 0; i < numBcns; ++i) stash_of(allBcns[i])->ops = ++h->bcnOps[slots[i]];
+    bool listed = false;
+    for (int i = 0; i < numBcns; ++i) listed |= (slots[i] == target);
+    if (!listed) stash_of(bcn)->ops = ++h->bcnOps[target];
 }
 
 }  // namespace
@@ -838,9 +933,9 @@ extern "C" void particleFilterSlam_init(particleFilterSlam_t* pf)
         h = pfx_slam_create(1, legacy_n("PF_HIP_N_TAG_SLAM", PF_N_TAG_SLAM), legacy_n("PF_HIP_N_BCN", PF_N_BCN), kSlamMaxBcns, nullptr,
                             seed, legacy_device());
         if (!h) { fail("particleFilterSlam_init"); return; }
-        SlamStash* s = stash_of(pf);
-        s->magic = kSlamMagic; s->self = (uint64_t)(uintptr_t)pf; s->handle = h;
     }
+    ++h->legacyOps;
+    bind_slam(pf, h);
     vio_store(pf, VioAcc());
     pf->initialized = 1;
 }
@@ -895,14 +990,10 @@ extern "C" uint8_t particleFilterSlam_getBcnLoc(const particleFilterSlam_t* pf, 
     if (!bcn->initialized) return 0;
     pfx_slam* h = must_be_bound(pf, "particleFilterSlam_getBcnLoc");
     if (!h) return 0;
-    const BcnStash* s = stash_of(bcn);
-    if (s->magic != kBcnMagic || s->self != (uint64_t)(uintptr_t)bcn || s->owner != h) {
-        set_error("particleFilterSlam_getBcnLoc: beacon %p has never been deposited to this filter", (const void*)bcn);
-        fail("particleFilterSlam_getBcnLoc");
-        return 0;
-    }
     DeviceGuard g(h->device);
-    const int slot = (int)s->slot;
+    // (a beacon that holds particles this filter has not seen -- a stored struct being continued -- is taken in here)
+    const int slot = slot_of(h, const_cast<bcn_t*>(bcn), "particleFilterSlam_getBcnLoc");
+    if (slot < 0) { fail("particleFilterSlam_getBcnLoc"); return 0; }
     if (bcn_pose_sums(h, &slot)) { fail("particleFilterSlam_getBcnLoc"); return 0; }
     bcn_pose_finish((const double*)h->hScratch, pf->lastT, t, x, y, z, theta);
     return 1;
@@ -931,6 +1022,9 @@ extern "C" int pfx_slam_sync_host(particleFilterSlam_t* pf, bcn_t* bcn)
             pf->pTag[i].w = tmp[i]; pf->pTag[i].x = tmp[n + i]; pf->pTag[i].y = tmp[2 * n + i];
             pf->pTag[i].z = tmp[3 * n + i]; pf->pTag[i].theta = tmp[4 * n + i];
         }
+        SlamStash* s = stash_of(pf);
+        s->ops = h->legacyOps; s->seed = h->fl[0].seed; s->epoch = h->fl[0].epoch;
+        s->syncedOps = s->ops;              // until the next state-changing call the struct is a complete checkpoint
     }
     if (bcn) {
         const int slot = pfx_slam_slot_of(pf, bcn);
@@ -942,6 +1036,9 @@ extern "C" int pfx_slam_sync_host(particleFilterSlam_t* pf, bcn_t* bcn)
         for (size_t i = 0; i < n; ++i) {
             p[i].w = tmp[i]; p[i].x = tmp[n + i]; p[i].y = tmp[2 * n + i]; p[i].z = tmp[3 * n + i]; p[i].theta = tmp[4 * n + i];
         }
+        BcnStash* bs = stash_of(bcn);
+        bs->ops = h->bcnOps[slot];
+        bs->syncedOps = bs->ops;
     }
     return 0;
 }
@@ -951,5 +1048,5 @@ extern "C" void pfx_slam_release(particleFilterSlam_t* pf)
     pfx_slam* h = bound(pf);
     if (!h) return;
     pfx_slam_destroy(h);
-    memset(stash_of(pf), 0, sizeof(SlamStash));
+    stash_of(pf)->handle = nullptr;         // the record stays: a struct that was synced to the host can still be continued
 }

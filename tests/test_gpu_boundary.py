@@ -241,3 +241,88 @@ def test_stale_struct_copy_is_refused_with_a_message():
     finally:
         L.pfx_set_abort_on_error(1)
     L.pfx_loc_release(pa)
+
+
+def _slam_run(L, pf_p, bcn_ps, calls):
+    """drive a particleFilterSlam_t / bcn_t set given by address; poses of the tag and of every beacon after each deposit"""
+    arr = (C.c_void_p * len(bcn_ps))(*[p.value for p in bcn_ps])
+    out = []
+    t = C.c_double()
+    v = [C.c_float() for _ in range(4)]
+    for c in calls:
+        if c[0] == "vio":
+            L.particleFilterSlam_depositTagVio(pf_p, *c[1:])
+            continue
+        L.particleFilterSlam_depositRange(pf_p, bcn_ps[c[1]], c[2], c[3], arr, len(bcn_ps))
+        row = []
+        ok = L.particleFilterSlam_getTagLoc(pf_p, C.byref(t), *[C.byref(q) for q in v])
+        row.append((int(ok),) + tuple(q.value for q in v))
+        for bp in bcn_ps:
+            ok = L.particleFilterSlam_getBcnLoc(pf_p, bp, C.byref(t), *[C.byref(q) for q in v])
+            row.append((int(ok),) + tuple(q.value for q in v))
+        out.append(row)
+    return out
+
+
+def _slam_calls(k0, k1):
+    calls = []
+    for k in range(k0, k1):
+        a = 0.05 * k
+        calls.append(("vio", 10.0 + 0.1 * k, float(np.cos(a)), float(np.sin(a)), 0.02 * k, 0.0))
+        calls.append(("range", k % 2, 3.0 + 0.2 * np.sin(0.3 * k + (k % 2)), 0.15))
+    return calls
+
+
+def test_slam_structs_checkpoint_and_continue():
+    """pfx_slam_sync_host makes particleFilterSlam_t and bcn_t complete checkpoints: their bytes, stored and brought back
+    at other addresses (or over the live structs), continue as the original did from there; copies taken without the
+    sync are refused with a message."""
+    from slam3d_amd import _lib, particlefilter as pfm, slam as sm
+    L = _lib.lib()
+    pfm.setSeed(4242)
+    f = sm.ParticleFilterSlam()
+    b = [f.addBcn(), f.addBcn()]
+    ps = [x._p for x in b]
+    _slam_run(L, f._p, ps, _slam_calls(0, 8))
+    stale = C.create_string_buffer(bytes(f._buf.raw), sm.SIZEOF_SLAM)          # copied without a sync
+    for x in b:
+        assert L.pfx_slam_sync_host(f._p, x._p) == 0
+    saved_f, saved_b = bytes(f._buf.raw), [bytes(x._buf.raw) for x in b]
+    rest = _slam_calls(8, 16)
+    ref = _slam_run(L, f._p, ps, rest)
+
+    def close(got):
+        d = max(abs(u - v) for ra, rb in zip(got, ref) for pa, pb in zip(ra, rb) for u, v in zip(pa, pb))
+        assert d <= 2e-5, d
+
+    # (1) at new addresses, the originals alive and ahead
+    f2 = C.create_string_buffer(saved_f, sm.SIZEOF_SLAM)
+    b2 = [C.create_string_buffer(x, sm.SIZEOF_BCN) for x in saved_b]
+    p2 = C.cast(f2, C.c_void_p)
+    got = _slam_run(L, p2, [C.cast(x, C.c_void_p) for x in b2], rest)
+    close(got)
+    assert L.pfx_slam_of(p2) and L.pfx_slam_of(p2) != L.pfx_slam_of(f._p)
+    L.pfx_slam_release(p2)
+    # (2) rolled back in place
+    h = L.pfx_slam_of(f._p)
+    C.memmove(f._buf, saved_f, sm.SIZEOF_SLAM)
+    for x, sv in zip(b, saved_b):
+        C.memmove(x._buf, sv, sm.SIZEOF_BCN)
+    close(_slam_run(L, f._p, ps, rest))
+    assert L.pfx_slam_of(f._p) == h
+    # (3) a copy without the particles
+    L.pfx_set_abort_on_error(0)
+    try:
+        n0 = L.pfx_error_count()
+        L.particleFilterSlam_depositRange(C.cast(stale, C.c_void_p), ps[0], 3.0, 0.1, (C.c_void_p * 2)(*[p.value for p in ps]), 2)
+        assert L.pfx_error_count() == n0 + 1 and b"pfx_slam_sync_host" in L.pfx_last_error()
+        # ... and a beacon copied without the sync, offered to a filter of its own
+        g = sm.ParticleFilterSlam()
+        _slam_run(L, f._p, ps, _slam_calls(16, 17))                              # the originals move on
+        bc = C.create_string_buffer(bytes(b[0]._buf.raw), sm.SIZEOF_BCN)
+        pc = C.cast(bc, C.c_void_p)
+        n0 = L.pfx_error_count()
+        L.particleFilterSlam_depositRange(g._p, pc, 3.0, 0.1, (C.c_void_p * 1)(pc.value), 1)
+        assert L.pfx_error_count() == n0 + 1 and b"pfx_slam_sync_host(pf, bcn)" in L.pfx_last_error()
+    finally:
+        L.pfx_set_abort_on_error(1)
