@@ -521,6 +521,61 @@ def test_resample_ragged_source_tiles(pfm, ora):
         assert np.array_equal(u, v), f"array {c}"
 
 
+def _random_ragged(n, seed):
+    """random weights with the features that stress the window logic: zero runs, tiny runs, spikes, a zero or heavy tail"""
+    rs = np.random.RandomState(seed)
+    w = rs.choice([0.0, 0.1, 0.5, 1.0], size=n, p=[0.2, 0.4, 0.2, 0.2]).astype(np.float32)
+    for _ in range(rs.randint(0, 6)):
+        a = rs.randint(0, n)
+        b = min(n, a + rs.randint(1, max(2, n // 3)))
+        w[a:b] = rs.choice([0.0, np.float32(2.0 ** -20), np.float32(3e-6), 0.05])
+    for _ in range(rs.randint(0, 4)):
+        w[rs.randint(0, n)] = rs.choice([5.0, 50.0, 1000.0])
+    if rs.rand() < 0.3:
+        w[-max(1, n // 7):] = 0.0
+    if not np.any(w > 0):
+        w[rs.randint(0, n)] = 1.0
+    return w
+
+
+@pytest.mark.parametrize("n", [1, 3, 1023, 1024, 1025, 2048, 4096 + 5, 10 * 1024, 23 * 1024 + 1000])
+def test_resample_random_ragged_weights(pfm, ora, n):
+    """Five random ragged weight sets per size, sizes around the tile boundaries: recorded ancestors equal the oracle's,
+    and the production pair (resampling on its own / fused into the next deposit) leaves bit-identical particles."""
+    for seed in range(5):
+        w = _random_ragged(n, 100 * n + seed)
+        rs = np.random.RandomState(seed)
+        x, y, z = (rs.uniform(-3, 3, n).astype(np.float32) for _ in range(3))
+        th = rs.uniform(0, 6.28, n).astype(np.float32)
+        g, o = _pair(pfm, ora, n)
+        _load(g, o, np.stack([w, x, y, z, th], axis=1), epoch=5 + seed)
+        g.record_ancestors(True)
+        rng_ = 2.0 if seed % 2 else 10.0                        # below 4 m a low mean weight also respawns 5 %
+        g.resample(0.5, -0.5, 0.2, rng_, 0.1)
+        o.resample(0.5, -0.5, 0.2, rng_, 0.1)
+        gs, os_ = g.last_stats(), o.last_stats()
+        assert int(gs["branch"]) == int(os_["branch"]) and int(gs["numSpawn"]) == int(os_["numSpawn"]), (n, seed)
+        assert gs["S"] == os_["S"], (n, seed)
+        if int(os_["branch"]):
+            assert gs["rStart"] == os_["rStart"] and gs["rStep"] == os_["rStep"], (n, seed)
+            assert np.array_equal(g.last_ancestors(), o.last_ancestors()), (n, seed)
+        fs = []
+        for deferred in (True, False):
+            f = pfm.DeviceParticleFilterLoc(n, seed=77 + seed)
+            f.set_deferred(deferred)
+            f.upload(w, x, y, z, th)
+            f.epoch = 3
+            f.set_force_branch(1)
+            f.depositVio(1.0, 0.0, 0.0, 0.0, 0.0)
+            f.depositRange(0.5, 0.2, 0.1, 3.0, 0.2)
+            f.depositVio(1.2, 0.1, -0.05, 0.02, 0.0)
+            f.depositRange(-1.0, 0.7, 0.0, 2.5, 0.1)
+            f.depositRssi(0.3, 0.3, 0.0, -60)
+            fs.append(f)
+        for c, (u, v) in enumerate(zip(fs[0].download(), fs[1].download())):
+            assert np.array_equal(u, v), (n, seed, c)
+
+
 @pytest.mark.parametrize("n", [10000, 50021])
 def test_deferred_sequence_tracks_oracle(pfm, ora, n):
     """The oracle comparison of test_deposit_sequence_tracks_oracle with the GPU pose read only every fifth
