@@ -236,6 +236,13 @@ int launch_stream(pfx_loc* pf, bool motion, bool gate, const Motion& mo, const G
 int launch_decide(pfx_loc* pf, float range, bool localOnly = false, bool pieces = false, int lo = 0, int hi = -1)
 {   // pieces: the per-tile sums come as pieces of the elements [lo, hi) produced here (+ sums of received elements)
     ProfScope ps(pf, PFX_K_DECIDE);
+    if (!localOnly && !pieces && pf->numShards == 1 && !pf->stageSlab && pf->numChunks <= kSmallChunks) {
+        // small filters: the two steps below in one launch of one workgroup (k_loc_decide_small)
+        hipExtLaunchKernelGGL(k_loc_decide_small, dim3(1), dim3(kChunkTiles), 0, pf->stream, ps.a(), ps.b(), 0, pf->ctl, pf->tileSums,
+                              pf->tileIncl, pf->chunkSums, pf->chunkBase, pf->destPlan, pf->numChunks, pf->numTiles, pf->n, range,
+                              key_of(pf), pf->force, pf->branchLog);
+        return check_launch("k_loc_decide_small");
+    }
     TilePieces tp{ nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
     if (pieces)
         tp = TilePieces{ pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles, pf->extraSums, lo, hi < 0 ? (int)pf->n : hi, (int)pf->n };

@@ -449,6 +449,40 @@ struct __attribute__((aligned(64))) DestPlan {
 };
 static_assert(sizeof(DestPlan) == 64, "one cache line per destination tile");
 
+// The plan record of destination tile d (k_loc_decide_map, k_loc_decide_small): base[] = chunk bases, tileIncl[] = tile
+// prefixes inside their chunk (global memory or LDS alike).
+__device__ __forceinline__ DestPlan plan_of_tile(int d, const double* base, const double* tileIncl, int numChunks, int numTiles,
+                                                 long long n, double rStart, double rStep, double S)
+{
+    const double u = rStart + rStep * (double)((long long)d * kTile);   // pfResample.c:71 at the tile's first offspring
+    // first chunk whose end value exceeds u, then the first tile inside it (the last tile if u is beyond every end value)
+    int lo = 0, hi = numChunks;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (base[mid + 1] > u) hi = mid; else lo = mid + 1;
+    }
+    int t = numTiles - 1;
+    if (lo < numChunks) {
+        int a = lo * kChunkTiles, b = (a + kChunkTiles < numTiles) ? a + kChunkTiles : numTiles;
+        const int last = b - 1;
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (tile_start_cdf(base, tileIncl, mid + 1, 0.0, S) > u) b = mid; else a = mid + 1;
+        }
+        t = a < last ? a : last;
+    }
+    DestPlan P;
+    P.t0 = t; P.pad = 0;
+    P.start0 = tile_start_cdf(base, tileIncl, t, 0.0, S);
+#pragma unroll
+    for (int i = 0; i < kPlanEnds; ++i) {
+        const int e = t + i + 1;
+        P.end[i] = tile_start_cdf(base, tileIncl, e < numTiles ? e : numTiles, 0.0, S);
+        P.upto[i] = (int)first_offspring_at(P.end[i], rStart, rStep, n);
+    }
+    return P;
+}
+
 // ------------------------------------------------------------------ decision + source map (unsharded filters)
 // The decision of an unsharded filter, whose resampling is destination-owned (resample_dest_tile below): besides the
 // scalars, a resampling step needs, for every destination tile d, the source tile that holds the ancestor of its
@@ -487,34 +521,76 @@ __global__ __launch_bounds__(kThreads) void k_loc_decide_map(LocCtl* __restrict_
     if (dec[0] == 0.0) return;
     const int d = blockIdx.x * kThreads + tid;
     if (d >= numTiles) return;
-    const double rStart = dec[1], rStep = dec[2], S = dec[3];
-    const double u = rStart + rStep * (double)((long long)d * kTile);   // pfResample.c:71 at the tile's first offspring
-    // first chunk whose end value exceeds u, then the first tile inside it (the last tile if u is beyond every end value)
-    int lo = 0, hi = numChunks;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (base[mid + 1] > u) hi = mid; else lo = mid + 1;
-    }
-    int t = numTiles - 1;
-    if (lo < numChunks) {
-        int a = lo * kChunkTiles, b = (a + kChunkTiles < numTiles) ? a + kChunkTiles : numTiles;
-        const int last = b - 1;
-        while (a < b) {
-            const int mid = (a + b) >> 1;
-            if (tile_start_cdf(base, tileIncl, mid + 1, 0.0, S) > u) b = mid; else a = mid + 1;
-        }
-        t = a < last ? a : last;
-    }
-    DestPlan P;
-    P.t0 = t; P.pad = 0;
-    P.start0 = tile_start_cdf(base, tileIncl, t, 0.0, S);
+    plan[d] = plan_of_tile(d, base, tileIncl, numChunks, numTiles, n, dec[1], dec[2], dec[3]);
+}
+
+// The same two steps -- k_loc_chunks, then k_loc_decide_map -- in ONE launch of ONE workgroup, for filters of at most
+// kSmallChunks chunks: one chunk, N <= 262 144, which is where the reference's own sizes lie (PF_N_TAG_LOC = 10 000).  There
+// a deposit is bound by its launches (three of ~5 us each) and a launch saved is a tenth of the step (measured at
+// N = 10 000: 33.4 -> 30.4 us per step of two deposits).  With four chunks (N <= 1 M) it lost -- 45.9 -> 64.5 us per step
+// at N = 1 M: one workgroup maps 977 destination tiles four deep where k_loc_decide_map has four.  Same functions on the same
+// values in the same order as the two kernels: the results are bit-identical, the arrays they leave in global memory
+// (tileIncl, chunkSums, chunkBase, plan) are those the big kernels expect; inside the kernel they travel through LDS.
+constexpr int kSmallChunks = 1;
+__global__ __launch_bounds__(kChunkTiles) void k_loc_decide_small(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
+                                                                 double* __restrict__ tileIncl, double* __restrict__ chunkSums,
+                                                                 double* __restrict__ chunkBase, DestPlan* __restrict__ plan,
+                                                                 int numChunks, int numTiles, long long n, float range, RngKey key,
+                                                                 int force, unsigned char* __restrict__ branchLog)
+{
+    __shared__ double red[4 * 7];
+    __shared__ double sc[4];
+    __shared__ double cs[kSmallChunks * kSumsPerTile];
+    __shared__ double inclS[kSmallChunks * kChunkTiles];
+    __shared__ double base[kSmallChunks + 1];
+    __shared__ double dec[4];
+    const int tid = threadIdx.x;
+    // all the tile sums first: one round trip
+    double v[kSmallChunks][7];
 #pragma unroll
-    for (int i = 0; i < kPlanEnds; ++i) {
-        const int e = t + i + 1;
-        P.end[i] = tile_start_cdf(base, tileIncl, e < numTiles ? e : numTiles, 0.0, S);
-        P.upto[i] = (int)first_offspring_at(P.end[i], rStart, rStep, n);
+    for (int c = 0; c < kSmallChunks; ++c) {
+        const int t = c * kChunkTiles + tid;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[c][k] = (c < numChunks && t < numTiles) ? tileSums[(size_t)t * kSumsPerTile + k] : 0.0;
     }
-    plan[d] = P;
+#pragma unroll
+    for (int c = 0; c < kSmallChunks; ++c) {
+        if (c < numChunks) {                                 // uniform; the body of k_loc_chunks for chunk c
+            const int t = c * kChunkTiles + tid;
+            double total;
+            double incl = block_inclusive_scan(v[c][0], sc, total);
+            __syncthreads();
+            incl = block_inclusive_max(incl, sc);
+            if (t < numTiles) { tileIncl[t] = incl; inclS[t] = incl; }
+            __syncthreads();
+            block_sum<7>(v[c], red);
+            if (tid == kChunkTiles - 1) { cs[c * kSumsPerTile] = incl; chunkSums[(size_t)c * kSumsPerTile] = incl; }
+            if (tid == 0) {
+#pragma unroll
+                for (int k = 1; k < 7; ++k) { cs[c * kSumsPerTile + k] = v[c][k]; chunkSums[(size_t)c * kSumsPerTile + k] = v[c][k]; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < 64) {                                          // the head of k_loc_decide_map
+        double tot[7];
+        chunk_prefix(cs, numChunks, tot, [&](int c, double b) { base[c] = b; chunkBase[c] = b; });
+        if (tid == 0) {
+            const Decision d = decide_compute(tot, n, range, key, force);
+            dec[0] = d.resample ? 1.0 : 0.0; dec[1] = d.rStart; dec[2] = d.rStep; dec[3] = d.S;
+            decide_commit(ctl, d, branchLog);
+            if (!d.resample) {
+                ctl->pose[0] = tot[0]; ctl->pose[1] = tot[4]; ctl->pose[2] = tot[5]; ctl->pose[3] = tot[6];
+                ctl->pose[4] = tot[2]; ctl->pose[5] = tot[3];
+            }
+            ctl->shardBase = 0.0; ctl->shardEnd = tot[0];
+            ctl->outBegin = 0; ctl->outEnd = n; ctl->selfBegin = 0; ctl->selfEnd = n; ctl->nGlobal = n;
+        }
+    }
+    __syncthreads();
+    if (dec[0] == 0.0) return;
+    for (int d = tid; d < numTiles; d += kChunkTiles)
+        plan[d] = plan_of_tile(d, base, inclS, numChunks, numTiles, n, dec[1], dec[2], dec[3]);
 }
 
 // ------------------------------------------------------------------ resample
