@@ -379,7 +379,9 @@ def _track_oracle(g, o, events, n, pose_every=1):
         for c in range(1, 4):
             assert np.abs(got[c] - exp[c]).max() <= 1e-5
     else:
-        q = np.linspace(0.05, 0.95, 19)
+        # (from the 10 % quantile on: after a deposit that respawns 5 % of the particles around a beacon, the 5 % quantile
+        # sits on the edge between that cluster and the cloud and moves by metres with a handful of particles)
+        q = np.linspace(0.10, 0.90, 17)
         for c in range(1, 4):
             assert np.abs(np.quantile(got[c], q) - np.quantile(exp[c], q)).max() < 0.05
     return k, diverged_at
@@ -583,6 +585,16 @@ def test_deferred_sequence_tracks_oracle(pfm, ora, n):
     g, o = _pair(pfm, ora, n)
     k, _ = _track_oracle(g, o, _scene_events(30), n, pose_every=5)
     assert k == 40
+
+
+def test_long_sequence_two_chunks_tracks_oracle(pfm, ora):
+    """300 000 particles (293 tiles: two chunks, so the three-launch path with k_loc_chunks + k_loc_decide_map) through 60
+    steps = 80 deposits, the pose read every seventh deposit: most resamplings run fused into the next deposit, with
+    the windows, respawn heads and tile counts a filter meets on its way from the spawn shell to tracking."""
+    n = 300000
+    g, o = _pair(pfm, ora, n)
+    k, _ = _track_oracle(g, o, _scene_events(60), n, pose_every=7)
+    assert k == 80
 
 
 def test_sequence_exact_until_first_gate_flip(pfm, ora):
