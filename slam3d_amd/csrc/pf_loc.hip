@@ -253,7 +253,7 @@ int launch_decide(pfx_loc* pf, float range, bool localOnly = false, bool pieces 
         hipExtLaunchKernelGGL((k_loc_decide<true>), dim3(1), dim3(kDecideThreads), 0, pf->stream, nullptr, ps.b(), 0, pf->ctl,
                               pf->chunkSums, pf->chunkBase, pf->numChunks, pf->n, range, key_of(pf), pf->force, pf->branchLog);
     else if (pf->numShards == 1 && !pf->stageSlab)
-        // unsharded: decision + source map of the destination-owned resampling
+        // unsharded: decision + plan records of the destination-owned resampling
         hipExtLaunchKernelGGL(k_loc_decide_map, dim3(pf->numChunks), dim3(kThreads), 0, pf->stream, nullptr, ps.b(), 0, pf->ctl,
                               pf->chunkSums, pf->chunkBase, pf->tileIncl, pf->destPlan, pf->numChunks, pf->numTiles, pf->n, range,
                               key_of(pf), pf->force, pf->branchLog);

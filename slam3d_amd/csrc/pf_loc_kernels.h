@@ -483,13 +483,13 @@ __device__ __forceinline__ DestPlan plan_of_tile(int d, const double* base, cons
     return P;
 }
 
-// ------------------------------------------------------------------ decision + source map (unsharded filters)
+// ------------------------------------------------------------------ decision + plan records (unsharded filters)
 // The decision of an unsharded filter, whose resampling is destination-owned (resample_dest_tile below): besides the
-// scalars, a resampling step needs, for every destination tile d, the source tile that holds the ancestor of its
-// first offspring.  Finding it inside the big kernel puts two to four dependent loads in front of everything else a
-// workgroup does; here it is one thread per destination tile, all of them at once.  Grid: one workgroup of 256 threads
-// per chunk of 256 tiles.  EVERY workgroup computes the chunk prefix and the decision (a pure function of the chunk
-// sums: same values everywhere) and keeps the chunk bases in LDS; workgroup 0 alone writes them, and the control block.
+// scalars, a resampling step needs the plan record of every destination tile (DestPlan above).  Working it out inside
+// the big kernel puts two to four dependent loads in front of everything else a workgroup does; here it is one thread
+// per destination tile, all of them at once.  Grid: one workgroup of 256 threads per chunk of 256 tiles.  EVERY workgroup
+// computes the chunk prefix and the decision (a pure function of the chunk sums: same values everywhere) and keeps the
+// chunk bases in LDS; workgroup 0 alone writes them, and the control block.
 __global__ __launch_bounds__(kThreads) void k_loc_decide_map(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
                                                             double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
                                                             DestPlan* __restrict__ plan, int numChunks, int numTiles, long long n,
