@@ -1039,6 +1039,9 @@ __device__ __forceinline__ int find_source_tile(const double* __restrict__ chunk
 #ifndef PF_OFFSPRING_UNROLL
 #define PF_OFFSPRING_UNROLL 4
 #endif
+#ifndef PF_SCHED_BARRIER_ALL
+#define PF_SCHED_BARRIER_ALL 0
+#endif
 #ifndef PF_DEPOSIT_TILES
 #define PF_DEPOSIT_TILES 1
 #endif
@@ -1252,6 +1255,9 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
                 acc[0] += ox[m]; acc[1] += oy[m]; acc[2] += oz[m]; acc[3] += cs; acc[4] += sn; acc[5] += 1.0;
             }
             ow[m] = wi;
+            // Without motion an offspring is little work and the scheduler runs all four at once: more values alive than
+            // the 72 registers of seven waves hold (25 spilled).  One offspring after the other, then.
+            if (DEPOSIT && (!MOTION || PF_SCHED_BARRIER_ALL)) __builtin_amdgcn_sched_barrier(0);
         }
         const size_t e = (size_t)lo + s * kTile + k0;
 #ifdef PF_EXP_NO_STORE          // timing experiment: the results stay alive, nothing is written
