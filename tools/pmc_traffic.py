@@ -84,14 +84,17 @@ def main():
     k, ls = launches("k_loc_resample_dest<false")
     put("resample", k, work(ls))
     # k_loc_deposit is one kernel with two sides (deferred resampling + deposit, or streaming pass only; the previous
-    # decision, on the device, picks).  With motion both sides read 20 B and write 20 B per particle and cannot be
-    # told apart by traffic: reported together.  Without motion the streaming side writes only the weights (4 B).
+    # decision, on the device, picks).  Both sides write 20 B per particle with motion; the streaming side reads exactly
+    # 20 B, the resampling side the source weights of ~3 tiles per destination tile on top of the gathered ancestors:
+    # launches that read more than 22 B per particle are resampling launches.  Without motion the streaming side writes
+    # only the weights (4 B).
     k, ls = launches("k_loc_deposit<true>")
-    put("resample_stream", k, work(ls), "; both sides of k_loc_deposit<motion> (streaming: 20 B read + 20 B written per particle; "
-        "resampling: source weights of the tiles a destination tile draws from + gathered ancestors read, 20 B written; the "
-        "doubling of FETCH_SIZE is calibrated for float4 streams, the dword gathers are covered by it only roughly)")
-    if "stream" not in out and "resample_stream" in out:
-        out["stream"] = dict(out["resample_stream"])
+    ls = work(ls)
+    put("resample_stream", k, [x for x in ls if x[0] > 22.0 * n], "; resampling side of k_loc_deposit<motion> (source weights of the "
+        "tiles a destination tile draws from + gathered ancestors read, 20 B written; the doubling of FETCH_SIZE is calibrated "
+        "for float4 streams, the dword gathers are covered by it only roughly)")
+    if "stream" not in out or out["stream"]["launches"] < 4:
+        put("stream", k, [x for x in ls if x[0] <= 22.0 * n], "; streaming side of k_loc_deposit<motion>")
     k, ls = launches("k_loc_deposit<false>")
     ls = work(ls)
     put("resample_static", k, [x for x in ls if x[1] > 12.0 * n], "; resampling side of k_loc_deposit<static>")
