@@ -549,6 +549,23 @@ __device__ __forceinline__ bool build_tile_cdf(const float (&w)[4], double tileS
     return small;
 }
 
+// The same selection for an offspring whose predecessor (the offspring before it, same table) was given ancestor
+// `prev`: positions do not decrease, so the answer is the first j >= prev with d < tab[j] -- three probes forward, and
+// the halving search only if that was not enough (a run of weightless particles in between).  Same result as
+// upper_bound_tile_u32 by construction.  The table needs four more entries of 0xFFFFFFFF behind its kTile.
+__device__ __forceinline__ int upper_bound_tile_u32_from(const uint32_t* tab, int n, uint32_t d, int prev)
+{
+    int p = prev;
+    if (!(d < tab[p])) {
+        ++p;
+        if (!(d < tab[p])) {
+            ++p;
+            if (!(d < tab[p])) return upper_bound_tile_u32(tab, n, d);
+        }
+    }
+    return p < n ? p : n - 1;
+}
+
 // ancestor of the offspring at CDF position u inside the tile whose table build_tile_cdf left in `tab`
 __device__ __forceinline__ int tile_ancestor(const double* tab, bool small, int nValid, double tileStart, double u)
 {
