@@ -1167,9 +1167,6 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
         for (int s = 0; s < NSUB; ++s) {
             if (NSUB == 1 || (upto > s * kTile && next < (s + 1) * kTile)) {            // uniform: tile s has offspring here
                 // The thread's offspring are consecutive: after the first one of them in this tile, the next one's ancestor is
-                // looked for from the previous one's on (three probes, the halving search if that was not enough): -2.7 % on
-                // the launch in the tracking scene, -1.6 .. -3.9 % under forced resampling, -2.4 % in the transient.
-                // The thread's offspring are consecutive: after the first one of them in this tile, the next one's ancestor is
                 // looked for from the previous one's on (three probes, then the halving search): -2.7 % on the launch in the
                 // tracking scene, -1.6 .. -3.9 % under forced resampling, -2.4 % in the transient after the spawn.
                 int prevJ = -1;                             // ancestor, inside this tile, of the thread's previous offspring
