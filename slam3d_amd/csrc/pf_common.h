@@ -390,6 +390,45 @@ __device__ __forceinline__ double block_sum_quads(const double (&v)[K], double* 
     return r;
 }
 
+// block_sum_quads for the LAST thing a workgroup does, on LDS nothing else has touched since the last barrier: the same
+// additions in the same order, but one barrier instead of three -- wavefronts 1 to 3 are done once their partial sums are
+// parked, wavefront 0 adds them up alone (a single wavefront runs in lockstep: its own LDS writes are ordered before its
+// reads by the wait on the LDS counter, no barrier needed).
+template <int K>
+__device__ __forceinline__ double block_sum_quads_tail(const double (&v)[K], double* lds)
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double s = v[k];
+        s += quad_perm_f64<0xB1>(s);
+        s += quad_perm_f64<0x4E>(s);
+        if ((tid & 3) == 0) lds[k * 64 + (tid >> 2)] = s;
+    }
+    __syncthreads();
+    double r = 0.0;
+    if (tid < 64) {
+        if (tid < K * 8) {
+            const int k = tid >> 3, j = tid & 7;
+            const double* p = lds + k * 64 + j;
+            double s = p[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) s += p[8 * i];
+            lds[k * 64 + j] = s;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tid < K) {
+            const double* p = lds + tid * 64;
+            r = p[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) r += p[j];
+        }
+    }
+    return r;
+}
+
 // Inclusive scan over the 64 lanes of a wavefront in six DPP steps, no LDS: row_shr 1, 2, 4, 8 inside each row of 16
 // lanes (a lane without a source adds the identity), then the last lane of rows 0 and 2 broadcast into rows 1 and 3
 // (row_bcast:15) and lane 31 into the upper half (row_bcast:31).  The sums it is used for are exact (integers, or

@@ -1287,7 +1287,7 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
                 if (k0 + m < cntS) ancOut[lo + s * kTile + k0 + m] = jg[s][m];
         }
         if (DEPOSIT) {
-            const double r = block_sum_quads<7>(acc, L.park);
+            const double r = (NSUB == 1) ? block_sum_quads_tail<7>(acc, L.park) : block_sum_quads<7>(acc, L.park);
             if (tid < 7) tileSums[(size_t)d * kSumsPerTile + tid] = r;
         } else if (POSE) {
             double pacc[6] = { acc[0], acc[1], acc[2], acc[3], acc[4], acc[5] };
