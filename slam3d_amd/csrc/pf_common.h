@@ -457,6 +457,20 @@ __device__ __forceinline__ T wave_inclusive_scan(T v)
     return v;
 }
 
+// Inclusive running maximum over the 64 lanes of a wavefront, same six steps, for values that are not negative (a lane
+// without a source compares against zero).
+__device__ __forceinline__ double wave_inclusive_max_nonneg(double v)
+{
+    double u;
+    u = dpp_or_zero<0x111, 0xf>(v); v = u > v ? u : v;
+    u = dpp_or_zero<0x112, 0xf>(v); v = u > v ? u : v;
+    u = dpp_or_zero<0x114, 0xf>(v); v = u > v ? u : v;
+    u = dpp_or_zero<0x118, 0xf>(v); v = u > v ? u : v;
+    u = dpp_or_zero<0x142, 0xa>(v); v = u > v ? u : v;
+    u = dpp_or_zero<0x143, 0xc>(v); v = u > v ? u : v;
+    return v;
+}
+
 // Inclusive scan of one double per thread across a 256-thread block.  `lds` holds 4 doubles.
 __device__ __forceinline__ double block_inclusive_scan(double v, double* lds, double& block_total)
 {
@@ -474,15 +488,12 @@ __device__ __forceinline__ double block_inclusive_scan(double v, double* lds, do
 }
 
 // Inclusive running maximum of one double per thread across a 256-thread block (exact: max is
-// associative).  Used to make a parallel prefix sum non-decreasing.  `lds` holds 4 doubles.
+// associative).  Used to make a parallel prefix sum of weights, which are not negative, non-decreasing.  `lds` holds
+// 4 doubles.
 __device__ __forceinline__ double block_inclusive_max(double v, double* lds)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double up = __shfl_up(v, off, 64);
-        if (lane >= off) v = up > v ? up : v;
-    }
+    v = wave_inclusive_max_nonneg(v);
     if (lane == 63) lds[wave] = v;
     __syncthreads();
     for (int k = 0; k < wave; ++k) v = lds[k] > v ? lds[k] : v;

@@ -254,7 +254,7 @@ int launch_decide(pfx_loc* pf, float range, bool localOnly = false, bool pieces 
                               pf->chunkSums, pf->chunkBase, pf->numChunks, pf->n, range, key_of(pf), pf->force, pf->branchLog);
     else if (pf->numShards == 1 && !pf->stageSlab)
         // unsharded: decision + plan records of the destination-owned resampling
-        hipExtLaunchKernelGGL(k_loc_decide_map, dim3(pf->numChunks), dim3(kThreads), 0, pf->stream, nullptr, ps.b(), 0, pf->ctl,
+        hipExtLaunchKernelGGL(k_loc_decide_map, dim3(pf->numChunks), dim3(kDecideMapThreads), 0, pf->stream, nullptr, ps.b(), 0, pf->ctl,
                               pf->chunkSums, pf->chunkBase, pf->tileIncl, pf->destPlan, pf->numChunks, pf->numTiles, pf->n, range,
                               key_of(pf), pf->force, pf->branchLog);
     else

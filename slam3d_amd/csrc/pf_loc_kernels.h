@@ -251,7 +251,10 @@ constexpr int kDecideThreads = 64;
 // force: -1 follow the reference's test, 0 never resample, 1 always resample (worst-case traffic runs).
 struct Decision { bool resample; int numSpawn; float s, ss, csum, ssum, ess, htheta, m; double S, rStart, rStep; };
 
-__device__ __forceinline__ Decision decide_compute(const double (&tot)[7], long long n, float range, const RngKey& key, int force)
+__device__ __forceinline__ float decide_uniform(const RngKey& key) { return uniform01(rng_block(key, P_RSTART, 0, 0).a); }
+
+// u01 = decide_uniform(key): a function of the key alone, so a caller can draw it while the sums are still on their way.
+__device__ __forceinline__ Decision decide_compute(const double (&tot)[7], long long n, float range, float u01, int force)
 {
     Decision d;
     d.S = tot[0];
@@ -272,7 +275,7 @@ __device__ __forceinline__ Decision decide_compute(const double (&tot)[7], long 
         h = h < 1.0f - 1e-10f ? h : 1.0f - 1e-10f;
         d.htheta = sqrtf(-logf(h) / d.ess);
         d.rStep = d.S / (double)n;
-        d.rStart = (double)uniform01(rng_block(key, P_RSTART, 0, 0).a) * d.rStep;
+        d.rStart = (double)u01 * d.rStep;
     } else {
         d.m = (float)n / d.s;       // pfResample.c:80-82, deferred: the next reader multiplies w by m
     }
@@ -299,35 +302,44 @@ __device__ __forceinline__ void decide_commit(LocCtl* __restrict__ ctl, const De
 __device__ __forceinline__ bool decide_scalars(LocCtl* __restrict__ ctl, const double (&tot)[7], long long n, float range,
                                                const RngKey& key, int force, unsigned char* __restrict__ branchLog)
 {
-    const Decision d = decide_compute(tot, n, range, key, force);
+    const Decision d = decide_compute(tot, n, range, decide_uniform(key), force);
     decide_commit(ctl, d, branchLog);
     return d.resample;
 }
 
 // Prefix over the chunk sums by ONE wavefront, no LDS, no barrier: lane l owns the chunks [l*per, (l+1)*per) (per = 1
-// up to 16.7 M particles).  The chunk bases are non-decreasing by construction: lane bases by a SEQUENTIAL prefix over
-// the 64 lane totals, values inside a lane by sequential adds capped at the next lane's base.  put(c, v) receives
+// up to 16.7 M particles).  The chunk bases are non-decreasing by construction: lane bases by a prefix over the 64 lane
+// totals followed by a running maximum, values inside a lane by sequential adds capped at the next lane's base.  put(c, v) receives
 // base c for c in [0, numChunks]; tot[] the seven totals (in every lane).
-template <typename Put>
-__device__ __forceinline__ void chunk_prefix(const double* __restrict__ chunkSums, int numChunks, double (&tot)[7], Put put)
+// meanwhile(): called once the loads of a lane's first chunk are on their way and before anything waits for them.
+template <typename Put, typename Meanwhile>
+__device__ __forceinline__ void chunk_prefix(const double* __restrict__ chunkSums, int numChunks, double (&tot)[7], Put put,
+                                             Meanwhile meanwhile)
 {
     const int lane = threadIdx.x & 63;
     const int per = (numChunks + 63) / 64;
     const int begin = min(lane * per, numChunks), end = min(begin + per, numChunks);
-    double loc[7] = { 0, 0, 0, 0, 0, 0, 0 };
-    for (int c = begin; c < end; ++c) {
+    double loc[7];
+    {
+        const double* p = chunkSums + (size_t)(begin < end ? begin : 0) * kSumsPerTile;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) loc[k] = p[k];
+        meanwhile();
+#pragma unroll
+        for (int k = 0; k < 7; ++k) loc[k] = begin < end ? loc[k] : 0.0;
+    }
+    for (int c = begin + 1; c < end; ++c) {
         const double* p = chunkSums + (size_t)c * kSumsPerTile;
 #pragma unroll
         for (int k = 0; k < 7; ++k) loc[k] += p[k];
     }
-    // sequential prefix over the lane totals (every lane computes the same 65 values)
-    double laneBase = 0.0, nextBase = 0.0, run = 0.0;
-    for (int l = 0; l < 64; ++l) {
-        const double t = __shfl(loc[0], l, 64);
-        if (l == lane) laneBase = run;
-        run += t;
-        if (l == lane) nextBase = run;
-    }
+    // prefix over the lane totals: six DPP steps, then a running maximum (a no-op while the sums are exact, section 4.1;
+    // beyond that it keeps the bases non-decreasing whatever the additions rounded to).  A loop over the 64 lanes, one
+    // readlane and one addition each, was 1 us of every deposit.
+    const double nextBase = wave_inclusive_max_nonneg(wave_inclusive_scan(loc[0]));
+    double laneBase = __shfl_up(nextBase, 1, 64);
+    if (lane == 0) laneBase = 0.0;
+    const double run = __shfl(nextBase, 63, 64);
     double v = laneBase;
     for (int c = begin; c < end; ++c) {
         put(c, v < nextBase ? v : nextBase);
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(64) void k_loc_decide(LocCtl* __restrict__ ctl, con
                                                   unsigned char* __restrict__ branchLog)
 {
     double tot[7];
-    chunk_prefix(chunkSums, numChunks, tot, [&](int c, double v) { chunkBase[c] = v; });
+    chunk_prefix(chunkSums, numChunks, tot, [&](int c, double v) { chunkBase[c] = v; }, [] {});
     if (threadIdx.x != 0) return;
     if (LOCAL_ONLY) {
         // sharded filter: publish the local sums; the decision is taken after the all-gather
@@ -421,6 +433,21 @@ __device__ __forceinline__ double tile_start_cdf(const double* __restrict__ chun
     return v < shardEnd ? v : shardEnd;
 }
 
+// The same value with the load unconditional (tileIncl[t - 1] exists for every t in [1, numTiles]; t = 0 reads entry 0
+// and drops it): a load behind a branch cannot be hoisted, and a sequence of these calls is then a sequence of round
+// trips.  For the plan records, where fifteen of them are wanted at once.
+__device__ __forceinline__ double tile_start_cdf_flat(const double* __restrict__ chunkBase, const double* __restrict__ tileIncl, int t,
+                                                      double shardEnd)
+{
+    const int c = t / kChunkTiles;
+    const double in = tileIncl[t > 0 ? t - 1 : 0];
+    const bool inside = t % kChunkTiles != 0;
+    const double b0 = chunkBase[c], cap = chunkBase[inside ? c + 1 : c];
+    double v = b0 + (inside ? in : 0.0);        // selections, no branch (the compiler sinks the load into one)
+    v = v < cap ? v : cap;
+    return v < shardEnd ? v : shardEnd;
+}
+
 // Number of offspring i in [0,n) with rStart + rStep*i < b (u_i is non-decreasing in i), i.e. the first
 // offspring that does not precede CDF value b.
 __device__ __forceinline__ long long first_offspring_at(double b, double rStart, double rStep, long long n)
@@ -429,6 +456,21 @@ __device__ __forceinline__ long long first_offspring_at(double b, double rStart,
     const double q = ceil((b - rStart) / rStep);
     if (!(q == q)) return 0;
     long long f = q < 0.0 ? 0 : (q > (double)n ? n : (long long)q);
+    for (int it = 0; it < 8 && f > 0 && !(rStart + rStep * (double)(f - 1) < b); ++it) --f;
+    for (int it = 0; it < 8 && f < n && (rStart + rStep * (double)f < b); ++it) ++f;
+    return f;
+}
+
+// The same count for n < 2^31 with the quotient estimated through invStep = 1 / rStep (one multiplication instead of a
+// float64 division, 32-bit conversions instead of 64-bit ones).  The estimate may be off by one where the division's
+// is exact; the two correction loops end at the same f either way, because f is defined by the comparisons alone.
+// The caller checks that invStep is finite.
+__device__ __forceinline__ int first_offspring_at_i32(double b, double rStart, double rStep, double invStep, int n)
+{
+    if (!((rStep > 0.0) && (rStep < 1e300))) return 0;
+    const double q = ceil((b - rStart) * invStep);
+    if (!(q == q)) return 0;
+    int f = q < 0.0 ? 0 : (q > (double)n ? n : (int)q);
     for (int it = 0; it < 8 && f > 0 && !(rStart + rStep * (double)(f - 1) < b); ++it) --f;
     for (int it = 0; it < 8 && f < n && (rStart + rStep * (double)f < b); ++it) ++f;
     return f;
@@ -449,38 +491,74 @@ struct __attribute__((aligned(64))) DestPlan {
 };
 static_assert(sizeof(DestPlan) == 64, "one cache line per destination tile");
 
-// The plan record of destination tile d (k_loc_decide_map, k_loc_decide_small): base[] = chunk bases, tileIncl[] = tile
-// prefixes inside their chunk (global memory or LDS alike).
-__device__ __forceinline__ DestPlan plan_of_tile(int d, const double* base, const double* tileIncl, int numChunks, int numTiles,
-                                                 long long n, double rStart, double rStep, double S)
+// The plan records of the destination tiles whose first offspring has its ancestor in chunk `chunk` (k_loc_decide_map:
+// one workgroup per chunk; k_loc_decide_small: the only chunk).  Worked from the SOURCE side: thread tid owns source
+// tile t = chunk * kChunkTiles + tid, takes the CDF value at its end and F_t, the number of offspring below that value
+// (one load, one first_offspring_at).  The offspring [F_(t-1), F_t) have their ancestors in tile t, so the destination
+// tiles d with d * kTile in that range -- those whose FIRST offspring does -- get the record of tile t: its bounds and
+// the (end, F) pairs of its three successors, from LDS.  This is the tile the search from the destination side finds
+// (the first tile whose end value exceeds u_d: d * kTile < F_t says exactly that), without the search: looking for tile t
+// from destination tile d took a halving search over the chunk bases and eight dependent loads from tileIncl, 8 us of
+// the 12 us this kernel took on a resampling deposit.
+// Called by every thread of the workgroup (barriers inside).  Threads kChunkTiles .. kChunkTiles + 3, where the workgroup
+// has them, work out what lies beyond the chunk: the three tiles after it and the offspring count at its start.
+// base[]: chunk bases (LDS); tileIncl: tile prefixes inside their chunk (global memory, or LDS for the small kernel).
+constexpr int kPlanDirect = 4;      // records a thread writes by itself; what a tile has beyond that the wavefront shares
+struct PlanLds { double end[kChunkTiles + 3]; int F[kChunkTiles + 4]; };
+__device__ __forceinline__ void plan_scatter(int chunk, const double* base, const double* tileIncl, DestPlan* __restrict__ plan,
+                                             int numTiles, long long n, double rStart, double rStep, double S, PlanLds& L)
 {
-    const double u = rStart + rStep * (double)((long long)d * kTile);   // pfResample.c:71 at the tile's first offspring
-    // first chunk whose end value exceeds u, then the first tile inside it (the last tile if u is beyond every end value)
-    int lo = 0, hi = numChunks;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (base[mid + 1] > u) hi = mid; else lo = mid + 1;
+    const int tid = threadIdx.x, last = numTiles - 1;
+    const double invStep = 1.0 / rStep;
+    const bool fast = invStep < 1e300;
+    // slot tid of L: tile chunk * kChunkTiles + tid (beyond the last tile: the last tile again); slot kChunkTiles + 3 of
+    // F: the count at the START of the chunk
+    const bool startSlot = tid == kChunkTiles + 3;
+    int t = chunk * kChunkTiles + tid;
+    t = t < last ? t : last;
+    const int e = startSlot ? chunk * kChunkTiles : t + 1;
+    const double endV = tile_start_cdf_flat(base, tileIncl, e, S);
+    int F;
+    if (fast) F = first_offspring_at_i32(endV, rStart, rStep, invStep, (int)n);
+    else F = (int)first_offspring_at(endV, rStart, rStep, n);
+    if (tid < kChunkTiles + 4) {
+        L.F[tid] = F;
+        if (!startSlot) L.end[tid] = endV;
     }
-    int t = numTiles - 1;
-    if (lo < numChunks) {
-        int a = lo * kChunkTiles, b = (a + kChunkTiles < numTiles) ? a + kChunkTiles : numTiles;
-        const int last = b - 1;
-        while (a < b) {
-            const int mid = (a + b) >> 1;
-            if (tile_start_cdf(base, tileIncl, mid + 1, 0.0, S) > u) b = mid; else a = mid + 1;
-        }
-        t = a < last ? a : last;
-    }
+    __syncthreads();
+    int dLo = 0, dHi = 0;
     DestPlan P;
     P.t0 = t; P.pad = 0;
-    P.start0 = tile_start_cdf(base, tileIncl, t, 0.0, S);
+    if (tid < kChunkTiles && chunk * kChunkTiles + tid <= last) {
+        const int Fprev = tid > 0 ? L.F[tid - 1] : (blockDim.x > kChunkTiles ? L.F[kChunkTiles + 3] : 0);
+        dLo = (Fprev + kTile - 1) / kTile;
+        dHi = t == last ? numTiles : (F + kTile - 1) / kTile;
+        const double chunkStart = base[chunk];
+        P.start0 = tid > 0 ? L.end[tid - 1] : (chunkStart < S ? chunkStart : S);
 #pragma unroll
-    for (int i = 0; i < kPlanEnds; ++i) {
-        const int e = t + i + 1;
-        P.end[i] = tile_start_cdf(base, tileIncl, e < numTiles ? e : numTiles, 0.0, S);
-        P.upto[i] = (int)first_offspring_at(P.end[i], rStart, rStep, n);
+        for (int i = 0; i < kPlanEnds; ++i) {
+            const int k = (t + i < last ? t + i : last) - chunk * kChunkTiles;
+            P.end[i] = L.end[k];
+            P.upto[i] = L.F[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kPlanDirect; ++k)
+            if (dLo + k < dHi) plan[dLo + k] = P;
     }
-    return P;
+    if (tid >= kChunkTiles) return;             // (whole wavefronts)
+    // a tile with more than kPlanDirect destination tiles (concentrated weight): its wavefront writes the rest together
+    unsigned long long more = __ballot(dHi - dLo > kPlanDirect);
+    while (more) {
+        const int l = __ffsll((long long)more) - 1;
+        more &= more - 1;
+        DestPlan Q;
+        Q.t0 = __shfl(P.t0, l, 64); Q.pad = 0;
+        Q.start0 = __shfl(P.start0, l, 64);
+#pragma unroll
+        for (int i = 0; i < kPlanEnds; ++i) { Q.end[i] = __shfl(P.end[i], l, 64); Q.upto[i] = __shfl(P.upto[i], l, 64); }
+        const int from = __shfl(dLo, l, 64) + kPlanDirect, to = __shfl(dHi, l, 64);
+        for (int d = from + (tid & 63); d < to; d += 64) plan[d] = Q;
+    }
 }
 
 // ------------------------------------------------------------------ decision + plan records (unsharded filters)
@@ -490,7 +568,8 @@ __device__ __forceinline__ DestPlan plan_of_tile(int d, const double* base, cons
 // per destination tile, all of them at once.  Grid: one workgroup of 256 threads per chunk of 256 tiles.  EVERY workgroup
 // computes the chunk prefix and the decision (a pure function of the chunk sums: same values everywhere) and keeps the
 // chunk bases in LDS; workgroup 0 alone writes them, and the control block.
-__global__ __launch_bounds__(kThreads) void k_loc_decide_map(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
+constexpr int kDecideMapThreads = kChunkTiles + 64;
+__global__ __launch_bounds__(kDecideMapThreads) void k_loc_decide_map(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
                                                             double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
                                                             DestPlan* __restrict__ plan, int numChunks, int numTiles, long long n,
                                                             float range, RngKey key, int force,
@@ -498,13 +577,16 @@ __global__ __launch_bounds__(kThreads) void k_loc_decide_map(LocCtl* __restrict_
 {
     __shared__ double base[kMaxChunks + 1];
     __shared__ double dec[4];
+    __shared__ PlanLds planLds;
     const int tid = threadIdx.x;
     if (tid < 64) {
         double tot[7];
         const bool first = blockIdx.x == 0;
-        chunk_prefix(chunkSums, numChunks, tot, [&](int c, double v) { base[c] = v; if (first) chunkBase[c] = v; });
+        float u01 = 0.0f;
+        chunk_prefix(chunkSums, numChunks, tot, [&](int c, double v) { base[c] = v; if (first) chunkBase[c] = v; },
+                     [&] { u01 = decide_uniform(key); });
         if (tid == 0) {
-            const Decision d = decide_compute(tot, n, range, key, force);
+            const Decision d = decide_compute(tot, n, range, u01, force);
             dec[0] = d.resample ? 1.0 : 0.0; dec[1] = d.rStart; dec[2] = d.rStep; dec[3] = d.S;
             if (first) {
                 decide_commit(ctl, d, branchLog);
@@ -519,9 +601,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_decide_map(LocCtl* __restrict_
     }
     __syncthreads();
     if (dec[0] == 0.0) return;
-    const int d = blockIdx.x * kThreads + tid;
-    if (d >= numTiles) return;
-    plan[d] = plan_of_tile(d, base, tileIncl, numChunks, numTiles, n, dec[1], dec[2], dec[3]);
+    plan_scatter(blockIdx.x, base, tileIncl, plan, numTiles, n, dec[1], dec[2], dec[3], planLds);
 }
 
 // The same two steps -- k_loc_chunks, then k_loc_decide_map -- in ONE launch of ONE workgroup, for filters of at most
@@ -544,6 +624,7 @@ __global__ __launch_bounds__(kChunkTiles) void k_loc_decide_small(LocCtl* __rest
     __shared__ double inclS[kSmallChunks * kChunkTiles];
     __shared__ double base[kSmallChunks + 1];
     __shared__ double dec[4];
+    __shared__ PlanLds planLds;
     const int tid = threadIdx.x;
     // all the tile sums first: one round trip
     double v[kSmallChunks][7];
@@ -574,9 +655,9 @@ __global__ __launch_bounds__(kChunkTiles) void k_loc_decide_small(LocCtl* __rest
     }
     if (tid < 64) {                                          // the head of k_loc_decide_map
         double tot[7];
-        chunk_prefix(cs, numChunks, tot, [&](int c, double b) { base[c] = b; chunkBase[c] = b; });
+        chunk_prefix(cs, numChunks, tot, [&](int c, double b) { base[c] = b; chunkBase[c] = b; }, [] {});
         if (tid == 0) {
-            const Decision d = decide_compute(tot, n, range, key, force);
+            const Decision d = decide_compute(tot, n, range, decide_uniform(key), force);
             dec[0] = d.resample ? 1.0 : 0.0; dec[1] = d.rStart; dec[2] = d.rStep; dec[3] = d.S;
             decide_commit(ctl, d, branchLog);
             if (!d.resample) {
@@ -589,8 +670,8 @@ __global__ __launch_bounds__(kChunkTiles) void k_loc_decide_small(LocCtl* __rest
     }
     __syncthreads();
     if (dec[0] == 0.0) return;
-    for (int d = tid; d < numTiles; d += kChunkTiles)
-        plan[d] = plan_of_tile(d, base, inclS, numChunks, numTiles, n, dec[1], dec[2], dec[3]);
+    static_assert(kSmallChunks == 1, "one workgroup scatters the plan records of one chunk");
+    plan_scatter(0, base, inclS, plan, numTiles, n, dec[1], dec[2], dec[3], planLds);
 }
 
 // ------------------------------------------------------------------ resample

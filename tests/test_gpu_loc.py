@@ -523,6 +523,55 @@ def test_resample_ragged_source_tiles(pfm, ora):
         assert np.array_equal(u, v), f"array {c}"
 
 
+def test_resample_ragged_across_chunks(pfm, ora):
+    """The same irregular weights over three chunks of 256 source tiles, with the irregularities AT the chunk boundaries:
+    empty tiles on both sides of one, a heavy particle in the first tile after it, a heavy particle in the last slot of a
+    chunk's last tile (its plan record goes to dozens of destination tiles and names tiles of the next chunk), tiny
+    tiles right behind it.  The plan records are written from the source side, one workgroup per chunk, and what lies
+    beyond a chunk comes from four extra threads: this is the case that checks them.  Ancestors equal the oracle's; the
+    production pair leaves bit-identical particles."""
+    t = 1024
+    n = 600 * t + 333
+    w = _ragged_weights(n)
+    w[255 * t: 257 * t] = 0.0
+    w[257 * t + 3] = 500.0
+    w[511 * t + 1023] = 800.0
+    w[512 * t: 515 * t] = np.float32(3 * 2.0 ** -20)
+    w[515 * t] = 2500.0                                         # more destination tiles than a thread writes by itself
+    rs = np.random.RandomState(13)
+    x, y, z = (rs.uniform(-3, 3, n).astype(np.float32) for _ in range(3))
+    th = rs.uniform(0, 6.28, n).astype(np.float32)
+    g, o = _pair(pfm, ora, n)
+    _load(g, o, np.stack([w, x, y, z, th], axis=1), epoch=5)
+    g.record_ancestors(True)
+    g.resample(0.0, 0.0, 0.0, 10.0, 0.1)
+    o.resample(0.0, 0.0, 0.0, 10.0, 0.1)
+    gs, os_ = g.last_stats(), o.last_stats()
+    assert int(gs["branch"]) == 1 and int(os_["branch"]) == 1
+    assert gs["S"] == os_["S"] and gs["rStart"] == os_["rStart"] and gs["rStep"] == os_["rStep"]
+    anc = g.last_ancestors()
+    assert np.array_equal(anc, o.last_ancestors())
+    first_src = anc[::1024] // 1024                             # source tile of every destination tile's first offspring
+    counts = np.bincount(first_src, minlength=n // 1024 + 1)
+    assert counts[515] > 4 and counts[511] > 4 and counts[257] >= 1, "heavy tiles should feed several destination tiles"
+    assert np.any((first_src[:-1] < 512) & (first_src[1:] >= 512)), "a destination tile boundary crosses a chunk boundary"
+    fs = []
+    for deferred in (True, False):
+        f = pfm.DeviceParticleFilterLoc(n, seed=78)
+        f.set_deferred(deferred)
+        f.upload(w, x, y, z, th)
+        f.epoch = 3
+        f.set_force_branch(1)
+        f.depositVio(1.0, 0.0, 0.0, 0.0, 0.0)
+        f.depositRange(0.5, 0.2, 0.1, 3.0, 0.2)
+        f.depositVio(1.2, 0.1, -0.05, 0.02, 0.0)
+        f.depositRange(-1.0, 0.7, 0.0, 2.5, 0.1)
+        f.depositRssi(0.3, 0.3, 0.0, -60)
+        fs.append(f)
+    for c, (u, v) in enumerate(zip(fs[0].download(), fs[1].download())):
+        assert np.array_equal(u, v), f"array {c}"
+
+
 def _random_ragged(n, seed):
     """random weights with the features that stress the window logic: zero runs, tiny runs, spikes, a zero or heavy tail"""
     rs = np.random.RandomState(seed)
@@ -540,7 +589,8 @@ def _random_ragged(n, seed):
     return w
 
 
-@pytest.mark.parametrize("n", [1, 3, 1023, 1024, 1025, 2048, 4096 + 5, 10 * 1024, 23 * 1024 + 1000])
+@pytest.mark.parametrize("n", [1, 3, 1023, 1024, 1025, 2048, 4096 + 5, 10 * 1024, 23 * 1024 + 1000, 256 * 1024 + 1,
+                               700 * 1024 + 77])
 def test_resample_random_ragged_weights(pfm, ora, n):
     """Five random ragged weight sets per size, sizes around the tile boundaries: recorded ancestors equal the oracle's,
     and the production pair (resampling on its own / fused into the next deposit) leaves bit-identical particles."""
