@@ -500,8 +500,9 @@ static_assert(sizeof(DestPlan) == 64, "one cache line per destination tile");
 // (the first tile whose end value exceeds u_d: d * kTile < F_t says exactly that), without the search: looking for tile t
 // from destination tile d took a halving search over the chunk bases and eight dependent loads from tileIncl, 8 us of
 // the 12 us this kernel took on a resampling deposit.
-// Called by every thread of the workgroup (barriers inside).  Threads kChunkTiles .. kChunkTiles + 3, where the workgroup
-// has them, work out what lies beyond the chunk: the three tiles after it and the offspring count at its start.
+// Called by every thread of the workgroup (one barrier inside; a caller that comes back for another chunk puts one in
+// between).  What lies beyond the chunk -- the three tiles after it and the offspring count at its start -- is worked out
+// by threads kChunkTiles .. kChunkTiles + 3 where the workgroup has them, else by threads 0 .. 3 in a second go.
 // base[]: chunk bases (LDS); tileIncl: tile prefixes inside their chunk (global memory, or LDS for the small kernel).
 constexpr int kPlanDirect = 4;      // records a thread writes by itself; what a tile has beyond that the wavefront shares
 struct PlanLds { double end[kChunkTiles + 3]; int F[kChunkTiles + 4]; };
@@ -511,26 +512,34 @@ __device__ __forceinline__ void plan_scatter(int chunk, const double* base, cons
     const int tid = threadIdx.x, last = numTiles - 1;
     const double invStep = 1.0 / rStep;
     const bool fast = invStep < 1e300;
-    // slot tid of L: tile chunk * kChunkTiles + tid (beyond the last tile: the last tile again); slot kChunkTiles + 3 of
-    // F: the count at the START of the chunk
-    const bool startSlot = tid == kChunkTiles + 3;
-    int t = chunk * kChunkTiles + tid;
-    t = t < last ? t : last;
-    const int e = startSlot ? chunk * kChunkTiles : t + 1;
-    const double endV = tile_start_cdf_flat(base, tileIncl, e, S);
-    int F;
-    if (fast) F = first_offspring_at_i32(endV, rStart, rStep, invStep, (int)n);
-    else F = (int)first_offspring_at(endV, rStart, rStep, n);
-    if (tid < kChunkTiles + 4) {
-        L.F[tid] = F;
-        if (!startSlot) L.end[tid] = endV;
+    // slot k of L, k < kChunkTiles + 3: tile chunk * kChunkTiles + k (beyond the last tile: the last tile again); slot
+    // kChunkTiles + 3 of F: the count at the START of the chunk
+    auto fill = [&](int slot, int& tOut, int& FOut) {
+        const bool startSlot = slot == kChunkTiles + 3;
+        int t = chunk * kChunkTiles + slot;
+        t = t < last ? t : last;
+        const double endV = tile_start_cdf_flat(base, tileIncl, startSlot ? chunk * kChunkTiles : t + 1, S);
+        int F;
+        if (fast) F = first_offspring_at_i32(endV, rStart, rStep, invStep, (int)n);
+        else F = (int)first_offspring_at(endV, rStart, rStep, n);
+        if (slot < kChunkTiles + 4) {
+            L.F[slot] = F;
+            if (!startSlot) L.end[slot] = endV;
+        }
+        tOut = t; FOut = F;
+    };
+    int t, F;
+    fill(tid, t, F);
+    if (blockDim.x == kChunkTiles && tid < 4) {     // a workgroup without the extra wavefront: four threads go twice
+        int t2, F2;
+        fill(kChunkTiles + tid, t2, F2);
     }
     __syncthreads();
     int dLo = 0, dHi = 0;
     DestPlan P;
     P.t0 = t; P.pad = 0;
     if (tid < kChunkTiles && chunk * kChunkTiles + tid <= last) {
-        const int Fprev = tid > 0 ? L.F[tid - 1] : (blockDim.x > kChunkTiles ? L.F[kChunkTiles + 3] : 0);
+        const int Fprev = tid > 0 ? L.F[tid - 1] : L.F[kChunkTiles + 3];
         dLo = (Fprev + kTile - 1) / kTile;
         dHi = t == last ? numTiles : (F + kTile - 1) / kTile;
         const double chunkStart = base[chunk];
@@ -561,6 +570,9 @@ __device__ __forceinline__ void plan_scatter(int chunk, const double* base, cons
     }
 }
 
+#ifndef PF_SMALL_CHUNKS
+#define PF_SMALL_CHUNKS 1
+#endif
 // ------------------------------------------------------------------ decision + plan records (unsharded filters)
 // The decision of an unsharded filter, whose resampling is destination-owned (resample_dest_tile below): besides the
 // scalars, a resampling step needs the plan record of every destination tile (DestPlan above).  Working it out inside
@@ -607,11 +619,13 @@ __global__ __launch_bounds__(kDecideMapThreads) void k_loc_decide_map(LocCtl* __
 // The same two steps -- k_loc_chunks, then k_loc_decide_map -- in ONE launch of ONE workgroup, for filters of at most
 // kSmallChunks chunks: one chunk, N <= 262 144, which is where the reference's own sizes lie (PF_N_TAG_LOC = 10 000).  There
 // a deposit is bound by its launches (three of ~5 us each) and a launch saved is a tenth of the step (measured at
-// N = 10 000: 33.4 -> 30.4 us per step of two deposits).  With four chunks (N <= 1 M) it lost -- 45.9 -> 64.5 us per step
-// at N = 1 M: one workgroup maps 977 destination tiles four deep where k_loc_decide_map has four.  Same functions on the same
-// values in the same order as the two kernels: the results are bit-identical, the arrays they leave in global memory
-// (tileIncl, chunkSums, chunkBase, plan) are those the big kernels expect; inside the kernel they travel through LDS.
-constexpr int kSmallChunks = 1;
+// N = 10 000: 33.4 -> 30.4 us per step of two deposits).  With four chunks (-DPF_SMALL_CHUNKS=4, N <= 1 M) it loses, also
+// with the plan records written from the source side: 36.7 -> 38.8 us per step at N = 500 000, 41.7 -> 58.1 at N = 1 M --
+// one workgroup takes the chunks one after the other (five barriers each) where the two kernels have a workgroup per
+// chunk.  Same functions on the same values in the same order as the two kernels: the results are bit-identical, the
+// arrays they leave in global memory (tileIncl, chunkSums, chunkBase, plan) are those the big kernels expect; inside the
+// kernel they travel through LDS.
+constexpr int kSmallChunks = PF_SMALL_CHUNKS;
 __global__ __launch_bounds__(kChunkTiles) void k_loc_decide_small(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
                                                                  double* __restrict__ tileIncl, double* __restrict__ chunkSums,
                                                                  double* __restrict__ chunkBase, DestPlan* __restrict__ plan,
@@ -670,8 +684,10 @@ __global__ __launch_bounds__(kChunkTiles) void k_loc_decide_small(LocCtl* __rest
     }
     __syncthreads();
     if (dec[0] == 0.0) return;
-    static_assert(kSmallChunks == 1, "one workgroup scatters the plan records of one chunk");
-    plan_scatter(0, base, inclS, plan, numTiles, n, dec[1], dec[2], dec[3], planLds);
+    for (int c = 0; c < numChunks; ++c) {
+        if (c > 0) __syncthreads();
+        plan_scatter(c, base, inclS, plan, numTiles, n, dec[1], dec[2], dec[3], planLds);
+    }
 }
 
 // ------------------------------------------------------------------ resample
