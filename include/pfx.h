@@ -131,14 +131,17 @@ int64_t  pfx_loc_branch_log(pfx_loc* pf, uint8_t* out, int64_t cap, int64_t* tot
  *   pfx_loc_shard_begin    VIO commit (returns 1 instead if the filter was uninitialised and has just spawned its
  *                          particles: nothing else follows)
  *   pfx_loc_shard_deposit  the O(N) pass, launched WITHOUT looking at the previous deposit's decision: after a
- *                          "resample" the kernel produces the offspring of the local ancestors and deposits on them in
- *                          the same pass (those whose index is outside the shard's own range are staged as
- *                          (x, y, z, theta) records, first those below the range, then those above it); after a
- *                          "normalise" it is the streaming pass
+ *                          "resample" the kernel produces the offspring of the local ancestors that fall into the shard's
+ *                          own index range and deposits on them in the same pass; after a "normalise" it is the streaming
+ *                          pass
  *   pfx_loc_shard_plan     the previous deposit's decision (it landed in pinned host memory while the kernel above was
  *                          launched): branch and F[g] = first global offspring index produced by shard g
  *                          (F[num_shards] = n_global).  Fails if the staging area is too small.
  *   after a "resample":
+ *     pfx_loc_shard_stage  if F says that some of this shard's offspring belong to other shards: they are produced as
+ *                          (x, y, z, theta) records in the send half of the staging area, first those below the shard's
+ *                          range, then those above it (a no-op under PFX_SHARD_DIRECT=0, where the deposit kernel is
+ *                          round 1's source-owned one and has staged them itself)
  *     shipping             the caller sends each neighbour its slice of the staging area into that shard's landing area
  *                          (record k of the landing area = local element k for k < lo, else hi + (k - lo), where
  *                          [lo, hi) are the elements the shard produced itself)
@@ -153,6 +156,7 @@ int64_t  pfx_loc_branch_log(pfx_loc* pf, uint8_t* out, int64_t cap, int64_t* tot
 int      pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64_t n_global, int64_t self_begin, int64_t stage_capacity);
 int      pfx_loc_shard_begin(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);
 int      pfx_loc_shard_deposit(pfx_loc* pf);
+int      pfx_loc_shard_stage(pfx_loc* pf);
 void*    pfx_loc_shard_local_ptr(pfx_loc* pf);      /* device address: s ss csum ssum wx wy wz 0 */
 void*    pfx_loc_shard_all_ptr(pfx_loc* pf);        /* device address: 16 x 8 doubles */
 int      pfx_loc_shard_decide(pfx_loc* pf);

@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
     sig("pfx_loc_shard_config", i, vp, i, i, i64, i64, i64)
     sig("pfx_loc_shard_begin", i, vp, f, f, f, f, f)
     sig("pfx_loc_shard_deposit", i, vp)
+    sig("pfx_loc_shard_stage", i, vp)
     sig("pfx_loc_shard_local_ptr", vp, vp)
     sig("pfx_loc_shard_all_ptr", vp, vp)
     sig("pfx_loc_shard_decide", i, vp)

@@ -146,6 +146,8 @@ struct pfx_loc {
     Gate shGa{};
     float shArg[5] = { 0, 0, 0, 0, 0 };
     double* extraSums = nullptr;    // numTiles * kSumsPerTile: sums of the received elements of each tile (k_loc_land)
+    bool stagePending = false;      // a destination-owned fused pass has run and its foreign offspring have not been staged
+    bool shardDirect = true;        // sharded filters: destination-owned fused pass (k_loc_deposit_shard); PFX_SHARD_DIRECT=0: round 1's
     // profiling
     std::vector<ProfRec> prof;
     size_t profUsed = 0;
@@ -243,9 +245,10 @@ int launch_decide(pfx_loc* pf, float range, bool localOnly = false, bool pieces 
                               key_of(pf), pf->force, pf->branchLog);
         return check_launch("k_loc_decide_small");
     }
-    TilePieces tp{ nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
+    TilePieces tp{ nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0 };
     if (pieces)
-        tp = TilePieces{ pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles, pf->extraSums, lo, hi < 0 ? (int)pf->n : hi, (int)pf->n };
+        tp = TilePieces{ pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles, pf->extraSums, lo, hi < 0 ? (int)pf->n : hi, (int)pf->n,
+                         pf->shardDirect ? 1 : 0 };
     hipExtLaunchKernelGGL(k_loc_chunks, dim3(pf->numChunks), dim3(kChunkTiles), 0, pf->stream, ps.a(), nullptr, 0, pf->tileSums,
                           pf->tileIncl, pf->chunkSums, pf->numTiles, pf->ctl, tp);
     if (check_launch("k_loc_chunks")) return -1;
@@ -854,9 +857,11 @@ extern "C" int pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64
         return -2;
     }
     if (self_begin < 0 || self_begin + pf->n > n_global) { set_error("pfx_loc_shard_config: index range outside [0, n_global)"); return -2; }
+    if (n_global > (1ll << 32)) { set_error("pfx_loc_shard_config: at most 2^32 particles in all (16 shards of 2^28)"); return -2; }
     DeviceGuard g(pf->device);
     if (materialise(pf)) return -1;
     pf->rank = rank; pf->numShards = num_shards; pf->nGlobal = n_global; pf->selfBegin = self_begin;
+    { const char* e = getenv("PFX_SHARD_DIRECT"); pf->shardDirect = !(e && e[0] == '0'); }
     if (!pf->dAll) {
         PF_HIP_OK(hipMalloc((void**)&pf->dAll, kMaxShards * 8 * sizeof(double)));
         PF_HIP_OK(hipHostMalloc((void**)&pf->hostPlan, sizeof(ShardPlan), hipHostMallocMapped));
@@ -931,6 +936,17 @@ extern "C" int pfx_loc_shard_deposit(pfx_loc* pf)
     const dim3 grid(pf->numTiles), block(kThreads);
     const float* a = pf->deferArg;
     const RespawnShell sh{ a[0], a[1], a[2], a[3], a[4] };
+    if (pf->shardDirect) {
+#define PF_LAUNCH_DSD(M) \
+    hipExtLaunchKernelGGL((k_loc_deposit_shard<M>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->tileSums, \
+                          pf->chunkBase, pf->tileIncl, pf->numTiles, (int)pf->n, (long long)pf->selfBegin, pf->deferKey, sh, key_of(pf), \
+                          pf->shMo, pf->shGa, pf->destPlan)
+        if (pf->shMotion) PF_LAUNCH_DSD(true);
+        else PF_LAUNCH_DSD(false);
+#undef PF_LAUNCH_DSD
+        pf->stagePending = true;        // the foreign offspring are produced by pfx_loc_shard_stage, if the plan has any
+        return check_launch("k_loc_deposit_shard");
+    }
     const PieceOut out{ pf->pieceSums, pf->pieceSlots, pf->pieceSlots + pf->numTiles };
 #define PF_LAUNCH_DS(M) \
     hipExtLaunchKernelGGL((k_loc_deposit_sharded<M>), grid, block, 0, pf->stream, ps.a(), ps.b(), 0, pf->bufs, pf->ctl, pf->tileSums, \
@@ -940,6 +956,24 @@ extern "C" int pfx_loc_shard_deposit(pfx_loc* pf)
     else PF_LAUNCH_DS(false);
 #undef PF_LAUNCH_DS
     return check_launch("k_loc_deposit_sharded");
+}
+
+// After pfx_loc_shard_deposit and pfx_loc_shard_plan, when the plan says "resample" and some of this shard's offspring
+// belong to other shards: produces them into the send half of the staging area (k_loc_stage_foreign).  The host calls
+// it only then -- it has read the plan by now -- so the other deposits are one launch shorter.  A no-op when the fused
+// pass was the source-owned one (PFX_SHARD_DIRECT=0), which stages on its way, and when no fused pass is outstanding.
+extern "C" int pfx_loc_shard_stage(pfx_loc* pf)
+{
+    clear_error();
+    if (shard_ready(pf, "pfx_loc_shard_stage")) return -2;
+    if (!pf->shardDirect || !pf->stagePending) return 0;
+    pf->stagePending = false;
+    DeviceGuard g(pf->device);
+    const float* a = pf->deferArg;
+    const RespawnShell sh{ a[0], a[1], a[2], a[3], a[4] };
+    hipLaunchKernelGGL(k_loc_stage_foreign, dim3((pf->numTiles + kThreads - 1) / kThreads), dim3(kThreads), 0, pf->stream, pf->bufs, pf->ctl,
+                       pf->chunkBase, pf->tileIncl, pf->numTiles, (int)pf->n, pf->deferKey, sh, stage_of(pf));
+    return check_launch("k_loc_stage_foreign");
 }
 
 extern "C" void* pfx_loc_shard_local_ptr(pfx_loc* pf) { return (void*)pf->ctl->local; }   // device address, 8 doubles
@@ -953,13 +987,23 @@ extern "C" int pfx_loc_shard_decide(pfx_loc* pf)
     if (shard_ready(pf, "pfx_loc_shard_decide")) return -2;
     DeviceGuard g(pf->device);
     ProfScope ps(pf, PFX_K_DECIDE);
-    hipExtLaunchKernelGGL(k_loc_shard_decide, dim3(1), dim3(64), 0, pf->stream, ps.a(), ps.b(), 0, pf->ctl, pf->dAll, pf->numShards,
-                          pf->rank, pf->nGlobal, pf->selfBegin, pf->selfBegin + pf->n, pf->shArg[3], key_of(pf), pf->force, pf->branchLog,
-                          pf->dPlanMapped, (unsigned long long)pf->epoch);
-    if (check_launch("k_loc_shard_decide")) return -1;
+    if (pf->shardDirect) {
+        // decision + the plan records of the destination-owned fused pass
+        hipExtLaunchKernelGGL(k_loc_shard_decide_plan, dim3(pf->numChunks), dim3(kDecideMapThreads), 0, pf->stream, ps.a(), ps.b(), 0, pf->ctl,
+                              pf->dAll, pf->numShards, pf->rank, pf->nGlobal, pf->selfBegin, pf->selfBegin + pf->n, pf->shArg[3], key_of(pf),
+                              pf->force, pf->branchLog, pf->dPlanMapped, (unsigned long long)pf->epoch, pf->chunkBase, pf->tileIncl,
+                              pf->destPlan, pf->numChunks, pf->numTiles, (int)pf->n);
+        if (check_launch("k_loc_shard_decide_plan")) return -1;
+    } else {
+        hipExtLaunchKernelGGL(k_loc_shard_decide, dim3(1), dim3(64), 0, pf->stream, ps.a(), ps.b(), 0, pf->ctl, pf->dAll, pf->numShards,
+                              pf->rank, pf->nGlobal, pf->selfBegin, pf->selfBegin + pf->n, pf->shArg[3], key_of(pf), pf->force, pf->branchLog,
+                              pf->dPlanMapped, (unsigned long long)pf->epoch);
+        if (check_launch("k_loc_shard_decide")) return -1;
+    }
     pf->deferKey = key_of(pf);                  // what the resampling will need if the decision calls for one
     for (int k = 0; k < 5; ++k) pf->deferArg[k] = pf->shArg[k];
     pf->shardPending = 1;
+    pf->stagePending = false;
     pf->planRead = false;
     pf->planSeq = (unsigned long long)pf->epoch;
     return 0;

@@ -189,7 +189,9 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
 //
 // Sharded filters: only the local elements [lo, hi) were produced here (pieces); the elements [0, lo) and [hi, n)
 // arrived from the neighbouring shards and k_loc_land summed them per tile into `extra`.
-struct TilePieces { const double* sums; const int* headSlot; const int* tailSlot; const double* extra; int lo, hi, n; };
+// direct (k_loc_deposit_shard): no pieces -- a tile some of whose elements were produced here has its (partial) sums in
+// tileSums already.
+struct TilePieces { const double* sums; const int* headSlot; const int* tailSlot; const double* extra; int lo, hi, n; int direct; };
 
 __global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(double* __restrict__ tileSums, double* __restrict__ tileIncl,
                                                            double* __restrict__ chunkSums, int numTiles,
@@ -205,7 +207,12 @@ __global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(double* __restrict__
             const int first = t * kTile, last = (first + kTile < pieces.n ? first + kTile : pieces.n) - 1;
             // (hi > lo: a shard without weight produces nothing, and then no piece of this round exists for any tile --
             // the head / tail slots would be those of an earlier resampling)
-            if (pieces.hi > pieces.lo && first < pieces.hi && last >= pieces.lo) {  // some of the tile was produced here
+            if (pieces.direct) {
+                if (pieces.hi > pieces.lo && first < pieces.hi && last >= pieces.lo) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) v[k] = p[k];
+                }
+            } else if (pieces.hi > pieces.lo && first < pieces.hi && last >= pieces.lo) {  // some of the tile was produced here
                 int h = pieces.headSlot[t], e = pieces.tailSlot[t];
                 h = h < 0 ? 0 : h;
                 e = e >= 2 * numTiles ? 2 * numTiles - 1 : e;
@@ -437,7 +444,7 @@ __device__ __forceinline__ double tile_start_cdf(const double* __restrict__ chun
 // and drops it): a load behind a branch cannot be hoisted, and a sequence of these calls is then a sequence of round
 // trips.  For the plan records, where fifteen of them are wanted at once.
 __device__ __forceinline__ double tile_start_cdf_flat(const double* __restrict__ chunkBase, const double* __restrict__ tileIncl, int t,
-                                                      double shardEnd)
+                                                      double shardEnd, double shardBase = 0.0)
 {
     const int c = t / kChunkTiles;
     const double in = tileIncl[t > 0 ? t - 1 : 0];
@@ -445,6 +452,7 @@ __device__ __forceinline__ double tile_start_cdf_flat(const double* __restrict__
     const double b0 = chunkBase[c], cap = chunkBase[inside ? c + 1 : c];
     double v = b0 + (inside ? in : 0.0);        // selections, no branch (the compiler sinks the load into one)
     v = v < cap ? v : cap;
+    v += shardBase;                             // (0.0 for an unsharded filter)
     return v < shardEnd ? v : shardEnd;
 }
 
@@ -504,23 +512,41 @@ static_assert(sizeof(DestPlan) == 64, "one cache line per destination tile");
 // between).  What lies beyond the chunk -- the three tiles after it and the offspring count at its start -- is worked out
 // by threads kChunkTiles .. kChunkTiles + 3 where the workgroup has them, else by threads 0 .. 3 in a second go.
 // base[]: chunk bases (LDS); tileIncl: tile prefixes inside their chunk (global memory, or LDS for the small kernel).
+//
+// One shard of a sharded filter (SHARDED; k_loc_shard_decide_plan): the tiles are the shard's, positions in the GLOBAL CDF are
+// shardBase + the local prefix, offspring counts are global and enter the records relative to the shard's first element
+// (clamped to [0, n]: the index of the destination ELEMENT in the shard's own arrays).  Only the destination tiles that
+// hold an offspring of a local ancestor, local elements [loL, hiL), get a record; the tile that loL falls into gets the
+// record of the source tile that produces offspring loL (its leading elements arrive from the shard below).
 constexpr int kPlanDirect = 4;      // records a thread writes by itself; what a tile has beyond that the wavefront shares
 struct PlanLds { double end[kChunkTiles + 3]; int F[kChunkTiles + 4]; };
+struct ShardSpan { double base, end; long long selfBegin, nGlobal, outBegin, outEnd; };
+template <bool SHARDED = false>
 __device__ __forceinline__ void plan_scatter(int chunk, const double* base, const double* tileIncl, DestPlan* __restrict__ plan,
-                                             int numTiles, long long n, double rStart, double rStep, double S, PlanLds& L)
+                                             int numTiles, long long n, double rStart, double rStep, double S, PlanLds& L,
+                                             const ShardSpan& sp = ShardSpan{})
 {
     const int tid = threadIdx.x, last = numTiles - 1;
     const double invStep = 1.0 / rStep;
-    const bool fast = invStep < 1e300;
+    const bool fast = !SHARDED && invStep < 1e300;
+    auto rel = [&](long long F) -> int { F -= sp.selfBegin; return F < 0 ? 0 : (F > n ? (int)n : (int)F); };
+    const int loL = SHARDED ? rel(sp.outBegin) : 0;
     // slot k of L, k < kChunkTiles + 3: tile chunk * kChunkTiles + k (beyond the last tile: the last tile again); slot
     // kChunkTiles + 3 of F: the count at the START of the chunk
     auto fill = [&](int slot, int& tOut, int& FOut) {
         const bool startSlot = slot == kChunkTiles + 3;
         int t = chunk * kChunkTiles + slot;
         t = t < last ? t : last;
-        const double endV = tile_start_cdf_flat(base, tileIncl, startSlot ? chunk * kChunkTiles : t + 1, S);
+        const double endV = SHARDED ? tile_start_cdf_flat(base, tileIncl, startSlot ? chunk * kChunkTiles : t + 1, sp.end, sp.base)
+                                    : tile_start_cdf_flat(base, tileIncl, startSlot ? chunk * kChunkTiles : t + 1, S);
         int F;
-        if (fast) F = first_offspring_at_i32(endV, rStart, rStep, invStep, (int)n);
+        if (SHARDED) {
+            // (the shard's first and last offspring are what the global plan says, as in resample_deposit_tile)
+            const long long Fg = (startSlot && chunk == 0) ? sp.outBegin
+                               : (!startSlot && chunk * kChunkTiles + slot >= last) ? sp.outEnd
+                               : first_offspring_at(endV, rStart, rStep, sp.nGlobal);
+            F = rel(Fg);
+        } else if (fast) F = first_offspring_at_i32(endV, rStart, rStep, invStep, (int)n);
         else F = (int)first_offspring_at(endV, rStart, rStep, n);
         if (slot < kChunkTiles + 4) {
             L.F[slot] = F;
@@ -541,9 +567,11 @@ __device__ __forceinline__ void plan_scatter(int chunk, const double* base, cons
     if (tid < kChunkTiles && chunk * kChunkTiles + tid <= last) {
         const int Fprev = tid > 0 ? L.F[tid - 1] : L.F[kChunkTiles + 3];
         dLo = (Fprev + kTile - 1) / kTile;
+        if (SHARDED && Fprev == loL && F > loL) dLo = loL / kTile;      // the tile that produces the shard's first own offspring
         dHi = t == last ? numTiles : (F + kTile - 1) / kTile;
-        const double chunkStart = base[chunk];
-        P.start0 = tid > 0 ? L.end[tid - 1] : (chunkStart < S ? chunkStart : S);
+        const double chunkStart = SHARDED ? base[chunk] + sp.base : base[chunk];
+        const double cdfEnd = SHARDED ? sp.end : S;
+        P.start0 = tid > 0 ? L.end[tid - 1] : (chunkStart < cdfEnd ? chunkStart : cdfEnd);
 #pragma unroll
         for (int i = 0; i < kPlanEnds; ++i) {
             const int k = (t + i < last ? t + i : last) - chunk * kChunkTiles;
@@ -614,6 +642,67 @@ __global__ __launch_bounds__(kDecideMapThreads) void k_loc_decide_map(LocCtl* __
     __syncthreads();
     if (dec[0] == 0.0) return;
     plan_scatter(blockIdx.x, base, tileIncl, plan, numTiles, n, dec[1], dec[2], dec[3], planLds);
+}
+
+// The global decision of a sharded filter (as k_loc_shard_decide) and the plan records of the shard's destination-owned
+// fused pass, one workgroup per chunk of the shard's tiles: every workgroup takes the decision from the gathered sums -- a
+// pure function of them, so all agree, as in k_loc_decide_map -- and keeps what the plan records need in LDS; workgroup 0
+// alone commits it to the control block and publishes the host's copy.  chunkBase: the shard's LOCAL chunk bases
+// (k_loc_decide<true>).  (As two launches the pair cost 4.5 + 4.9 us of every deposit.)
+__global__ __launch_bounds__(kDecideMapThreads) void k_loc_shard_decide_plan(LocCtl* __restrict__ ctl, const double* __restrict__ all,
+                                                                             int numShards, int rank, long long nGlobal,
+                                                                             long long selfBegin, long long selfEnd, float range,
+                                                                             RngKey key, int force, unsigned char* __restrict__ branchLog,
+                                                                             ShardPlan* hostPlan, unsigned long long seq,
+                                                                             const double* __restrict__ chunkBase,
+                                                                             const double* __restrict__ tileIncl,
+                                                                             DestPlan* __restrict__ plan, int numChunks, int numTiles, int n)
+{
+    __shared__ double base[kMaxChunks + 1];
+    __shared__ PlanLds planLds;
+    __shared__ double decD[6];          // resample, rStart, rStep, S, shardBase, shardEnd
+    __shared__ long long decL[2];       // outBegin, outEnd
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        double tot[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        double gb[kMaxShards + 1];
+        gb[0] = 0.0;
+        for (int g = 0; g < numShards; ++g) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) tot[k] += all[g * 8 + k];
+            gb[g + 1] = tot[0];                     // sequential prefix: non-decreasing, gb[G] == S exactly
+        }
+        const Decision d = decide_compute(tot, nGlobal, range, decide_uniform(key), force);
+        auto first_of = [&](int g) -> long long {
+            if (!d.resample) return 0;
+            return (g == 0) ? 0 : (g == numShards ? nGlobal : first_offspring_at(gb[g], d.rStart, d.rStep, nGlobal));
+        };
+        const long long ob = first_of(rank), oe = first_of(rank + 1);
+        decD[0] = d.resample ? 1.0 : 0.0; decD[1] = d.rStart; decD[2] = d.rStep; decD[3] = d.S;
+        decD[4] = gb[rank]; decD[5] = gb[rank + 1];
+        decL[0] = ob; decL[1] = oe;
+        if (blockIdx.x == 0) {
+            decide_commit(ctl, d, branchLog);
+            if (!d.resample) {  // local part of the pose sums; the host all-reduces them when a pose is asked for
+                const double* l = ctl->local;
+                ctl->pose[0] = l[0]; ctl->pose[1] = l[4]; ctl->pose[2] = l[5]; ctl->pose[3] = l[6]; ctl->pose[4] = l[2]; ctl->pose[5] = l[3];
+            }
+            hostPlan->branch = d.resample ? 1 : 0;
+            hostPlan->numSpawn = d.numSpawn; hostPlan->htheta = d.htheta; hostPlan->wscale = d.resample ? 1.0f : d.m;
+            hostPlan->S = tot[0]; hostPlan->rStart = d.rStart; hostPlan->rStep = d.rStep;
+            for (int g = 0; g <= numShards; ++g) hostPlan->F[g] = (g == rank) ? ob : (g == rank + 1) ? oe : first_of(g);
+            ctl->shardBase = gb[rank]; ctl->shardEnd = gb[rank + 1];
+            ctl->outBegin = ob; ctl->outEnd = oe;
+            ctl->selfBegin = selfBegin; ctl->selfEnd = selfEnd; ctl->nGlobal = nGlobal;
+            __threadfence_system();
+            __hip_atomic_store(&hostPlan->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    for (int c = tid; c <= numChunks; c += kDecideMapThreads) base[c] = chunkBase[c];
+    __syncthreads();
+    if (decD[0] == 0.0) return;
+    const ShardSpan sp{ decD[4], decD[5], selfBegin, nGlobal, decL[0], decL[1] };
+    plan_scatter<true>(blockIdx.x, base, tileIncl, plan, numTiles, n, decD[1], decD[2], decD[3], planLds, sp);
 }
 
 // The same two steps -- k_loc_chunks, then k_loc_decide_map -- in ONE launch of ONE workgroup, for filters of at most
@@ -881,13 +970,14 @@ struct ResampleDepositLds {
 // SHARDED: the filter is one shard of a larger one (global indices selfBegin + local element).  Offspring whose index
 // falls outside the shard's own range are not deposited on here: they go to the staging area as they come out of the
 // resampling, and the shard that owns them deposits on them when they land (k_loc_land).
-template <bool MOTION, bool SHARDED>
+// STAGE_ONLY (k_loc_stage_foreign): source tile t's offspring that belong to other shards, and nothing else.
+template <bool MOTION, bool SHARDED, bool STAGE_ONLY = false>
 __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const LocCtl* __restrict__ ctl,
                                                       const double* __restrict__ chunkBase,
                                                       const double* __restrict__ tileIncl, int numTiles, int n,
                                                       const RngKey& keyRs, const RespawnShell& sh, const RngKey& key,
                                                       const Motion& mo, const Gate& ga, const PieceOut& out,
-                                                      const StagePtrs& stage, ResampleDepositLds& L)
+                                                      const StagePtrs& stage, ResampleDepositLds& L, int t)
 {
     double* const cdf = L.cdf;
     float4* const anc = L.anc;
@@ -898,7 +988,7 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
     int* __restrict__ headSlot = out.headSlot;
     int* __restrict__ tailSlot = out.tailSlot;
     const float sbx = sh.bx, sby = sh.by, sbz = sh.bz, srange = sh.range, sstd = sh.stdRange;
-    const int t = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int src = ctl->src, dst = ctl->dst;
     const int tbase = t * kTile;
     const int e0 = tbase + tid * kPerThread;
@@ -962,6 +1052,7 @@ __device__ __forceinline__ void resample_deposit_tile(const LocBufs& bufs, const
         }
     }
 
+    if (STAGE_ONLY) return;
     if (i0 >= i1) {
         // empty span at offspring position i0: a zero piece in the slot the walk would have used there
         if (tid < 7) pieceSums[(size_t)(t + i0 / kTile) * kSumsPerTile + tid] = 0.0;
@@ -1123,13 +1214,14 @@ __device__ __forceinline__ int wave_first_true(int a, int b, Pred pred)
 
 // the source tile whose CDF span [tile start, tile end) holds position u: first tile whose end value exceeds u
 // (the last tile if there is none: offspring that fall off the end, and every offspring of a filter without weight)
+// cdfBase, cdfEnd: 0 and the total weight, or a shard's span of the global CDF
 __device__ __forceinline__ int find_source_tile(const double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
-                                                int numChunks, int numTiles, double S, double u)
+                                                int numChunks, int numTiles, double cdfBase, double cdfEnd, double u)
 {
-    int c = wave_first_true(0, numChunks, [&](int k) { return chunkBase[k + 1] > u; });
+    int c = wave_first_true(0, numChunks, [&](int k) { return chunkBase[k + 1] + cdfBase > u; });
     if (c >= numChunks) return numTiles - 1;
     const int t0 = c * kChunkTiles, t1 = (t0 + kChunkTiles < numTiles) ? t0 + kChunkTiles : numTiles;
-    const int t = wave_first_true(t0, t1, [&](int k) { return tile_start_cdf(chunkBase, tileIncl, k + 1, 0.0, S) > u; });
+    const int t = wave_first_true(t0, t1, [&](int k) { return tile_start_cdf(chunkBase, tileIncl, k + 1, cdfBase, cdfEnd) > u; });
     return t < t1 ? t : t1 - 1;
 }
 
@@ -1158,7 +1250,12 @@ struct DestLds {
 // NSUB: destination tiles per workgroup (consecutive ones: blockIdx.x * NSUB + s).  With two, the dependent loads in front
 // of the arithmetic (record -> weights -> ancestors) are paid once per 2048 offspring, the second tile's ancestors are in
 // flight while the first tile is computed, and three source tiles are scanned per workgroup instead of four.
-template <int NSUB, bool DEPOSIT, bool MOTION, bool RECORD, bool POSE>
+// SHARDED (one shard of a sharded filter, k_loc_deposit_shard): the tiles are the shard's own, global offspring index =
+// selfBegin + local element (positions u, Philox counters and the respawn test use it), CDF values are global
+// (shardBase + local prefix), and only the elements [loL, hiL) -- the offspring of local ancestors that land in the
+// shard's own arrays -- are produced: the rest of a boundary tile is left zero here and written by k_loc_land when the
+// neighbours' records arrive, and its sums are a partial sum (k_loc_chunks adds what k_loc_land summed).
+template <int NSUB, bool DEPOSIT, bool MOTION, bool RECORD, bool POSE, bool SHARDED = false>
 __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const LocCtl* __restrict__ ctl,
                                                    const double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
                                                    int numTiles, int n, const RngKey& keyRs, const RespawnShell& sh,
@@ -1175,6 +1272,21 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
     const int lo = d0 * kTile;
     const int cnt = (n - lo < NSUB * kTile) ? n - lo : NSUB * kTile;    // offspring of this workgroup that exist
     const int k0 = tid * kPerThread;        // the thread's offspring: lo + s * kTile + k0 + m, s < NSUB, m < 4
+    static_assert(!SHARDED || (NSUB == 1 && !RECORD && !POSE), "the sharded form is the plain fused deposit");
+    const long long gOff = SHARDED ? ctl->selfBegin : 0;                // global index of local element 0
+    // A sharded filter has at most 16 x 2^28 = 2^32 particles (pfx_loc_shard_config checks it): global indices fit 32 bits
+    // unsigned, and the sharded form differs from the unsharded one in nothing but a uniform offset.
+    const uint32_t gLo = (uint32_t)(gOff + lo);                         // global index of the workgroup's first offspring
+    auto idx = [&](int k) -> uint64_t { return SHARDED ? (uint64_t)(gLo + (uint32_t)k) : (uint64_t)(lo + k); };
+    auto pos = [&](int k) -> double { return SHARDED ? (double)(gLo + (uint32_t)k) : (double)(lo + k); };
+    // [pBegin, pEnd): the workgroup's offspring (relative to lo) that are produced here
+    int pBegin = 0, pEnd = cnt;
+    if (SHARDED) {
+        auto rel = [&](long long g) -> int { g -= gOff + lo; return g < 0 ? 0 : (g > cnt ? cnt : (int)g); };
+        pBegin = rel(ctl->outBegin);
+        pEnd = rel(ctl->outEnd);
+        pEnd = pEnd > pBegin ? pEnd : pBegin;
+    }
 
     int jg[NSUB][4];
 #pragma unroll
@@ -1184,8 +1296,14 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
 
     // offspring below numSpawn are respawned on the range shell and need no ancestor (pfResample.c:75-76), unless the
     // ancestors are being recorded (the reference selects one for them too, :70-72, before it overwrites them)
-    int next = RECORD ? 0 : numSpawn - lo;
-    next = next < 0 ? 0 : (next > cnt ? cnt : next);
+    int next;
+    if (SHARDED) {
+        const long long ns = (long long)numSpawn - gOff - lo;
+        next = ns < pBegin ? pBegin : (ns > pEnd ? pEnd : (int)ns);
+    } else {
+        next = RECORD ? 0 : numSpawn - lo;
+        next = next < 0 ? 0 : (next > cnt ? cnt : next);
+    }
     const float* __restrict__ sw = bufs.p(src, 0);
     // Every wavefront works the tile sequence out for itself (uniform values, loads that hit the same lines): nothing
     // but the CDF table goes through LDS, and its two barriers per tile are the only ones of the loop.
@@ -1209,8 +1327,8 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
 #pragma unroll
         for (int m = 0; m < kAhead1; ++m)
             if (k0 + m < cnt) {
-                jitter_normals(keyRs, (uint64_t)(lo + k0 + m), nj[m]);
-                if (DEPOSIT && MOTION) vio_normals(key, (uint64_t)(lo + k0 + m), nv[m]);
+                jitter_normals(keyRs, idx(k0 + m), nj[m]);
+                if (DEPOSIT && MOTION) vio_normals(key, idx(k0 + m), nv[m]);
             }
     }
 #ifdef PF_EXP_IDENTITY_ANC      // timing experiment: no selection at all, offspring k descends from particle k
@@ -1220,13 +1338,13 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
         for (int m = 0; m < 4; ++m) jg[s][m] = (lo + s * kTile + k0 + m < n) ? lo + s * kTile + k0 + m : 0;
     next = cnt;
 #endif
-    while (next < cnt) {                                    // uniform over the workgroup
+    while (next < pEnd) {                                   // uniform over the workgroup
         // The source tile of offspring `next`: the first tile from tPrev + 1 on whose end value exceeds its position (the
         // last tile if there is none), and `upto`, how far that tile gets: the first offspring whose position is not
         // below the tile's end value (u is non-decreasing in k).  The record of this destination tile answers both for
         // the tiles t0 .. t0 + 3 with integer comparisons (tile t0 + i takes offspring `next` iff next < upto[i]); beyond
         // them the tile bounds are loaded, successors probed 64 at a time, and upto found by arithmetic on 64 lanes.
-        int t = -1, upto = cnt;
+        int t = -1, upto = pEnd;
         double tileStart = 0.0, tileEnd = 0.0;
 #pragma unroll
         for (int i = 0; i < kPlanEnds; ++i) {
@@ -1236,19 +1354,21 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
                 tileStart = (i == 0) ? P.start0 : P.end[i - 1];
                 tileEnd = P.end[i];
                 const int rel = P.upto[i] - lo;
-                upto = (ti >= numTiles - 1 || rel > cnt) ? cnt : rel;
+                upto = (ti >= numTiles - 1 || rel > pEnd) ? pEnd : rel;
             }
         }
         if (t < 0) {
-            const double un = rStart + rStep * (double)(lo + next);
+            // (the shard's span of the global CDF is read here, where it is needed: beyond the record's four tiles)
+            const double cdfBase = SHARDED ? ctl->shardBase : 0.0, cdfEnd = SHARDED ? ctl->shardEnd : S;
+            const double un = rStart + rStep * pos(next);
             const int a = (tPrev + 1 > P.t0 + kPlanEnds) ? tPrev + 1 : P.t0 + kPlanEnds;
             const int b = (a + 64 < numTiles) ? a + 64 : numTiles;
-            t = wave_first_true(a, b, [&](int k) { return tile_start_cdf(chunkBase, tileIncl, k + 1, 0.0, S) > un; });
-            if (t >= b) t = (b == numTiles) ? numTiles - 1 : find_source_tile(chunkBase, tileIncl, numChunks, numTiles, S, un);
-            tileStart = tile_start_cdf(chunkBase, tileIncl, t, 0.0, S);
-            tileEnd = tile_start_cdf(chunkBase, tileIncl, t + 1, 0.0, S);
-            upto = (t == numTiles - 1) ? cnt
-                                       : wave_first_true(next + 1, cnt, [&](int k) { return !(rStart + rStep * (double)(lo + k) < tileEnd); });
+            t = wave_first_true(a, b, [&](int k) { return tile_start_cdf(chunkBase, tileIncl, k + 1, cdfBase, cdfEnd) > un; });
+            if (t >= b) t = (b == numTiles) ? numTiles - 1 : find_source_tile(chunkBase, tileIncl, numChunks, numTiles, cdfBase, cdfEnd, un);
+            tileStart = tile_start_cdf(chunkBase, tileIncl, t, cdfBase, cdfEnd);
+            tileEnd = tile_start_cdf(chunkBase, tileIncl, t + 1, cdfBase, cdfEnd);
+            upto = (t == numTiles - 1) ? pEnd
+                                       : wave_first_true(next + 1, pEnd, [&](int k) { return !(rStart + rStep * pos(k) < tileEnd); });
         }
         const bool lastTile = t == numTiles - 1;
         const float4 w4 = (t == tFirst) ? wFirst : (t == tAhead) ? wAhead : *reinterpret_cast<const float4*>(sw + (size_t)t * kTile + k0);
@@ -1271,7 +1391,7 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
                 for (int m = 0; m < 4; ++m) {
                     const int k = s * kTile + k0 + m;
                     if (k >= next && k < upto) {
-                        const double u = rStart + rStep * (double)(lo + k);             // pfResample.c:71
+                        const double u = rStart + rStep * pos(k);                       // pfResample.c:71
                         int j;
                         if (small && prevJ >= 0)
                             j = upper_bound_tile_u32_from(reinterpret_cast<const uint32_t*>(L.tab), nValid,
@@ -1310,8 +1430,8 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
 #pragma unroll
     for (int m = kAhead1; m < kAhead; ++m)                  // while the ancestors are on their way
         if (k0 + m < cnt) {
-            jitter_normals(keyRs, (uint64_t)(lo + k0 + m), nj[m]);
-            if (DEPOSIT && MOTION) vio_normals(key, (uint64_t)(lo + k0 + m), nv[m]);
+            jitter_normals(keyRs, idx(k0 + m), nj[m]);
+            if (DEPOSIT && MOTION) vio_normals(key, idx(k0 + m), nv[m]);
         }
     const bool smallTurn = mo.stdTheta <= 1e-4f;
 #pragma unroll
@@ -1325,11 +1445,13 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
         for (int m = 0; m < 4; ++m) {
             const int k = k0 + m;
             ow[m] = ox[m] = oy[m] = oz[m] = ot[m] = 0.0f;
-            if (k >= cntS) continue;                        // pad elements of the last tile stay zero
+            // pad elements of the last tile stay zero; so do, in a shard, those another shard produces (k_loc_land writes
+            // them).  One unsigned comparison either way: a second condition here cost twelve spilled registers.
+            if (SHARDED ? (unsigned)(k - pBegin) >= (unsigned)(pEnd - pBegin) : k >= cntS) continue;
             const int g = lo + s * kTile + k;
-            const uint64_t gi = (uint64_t)g;
+            const uint64_t gi = idx(s * kTile + k);         // global index: the Philox counter
             const bool ahead = m < kAhead;                  // this offspring's unit normals have been drawn already
-            if (g < numSpawn) {
+            if (SHARDED ? (uint32_t)gi < (uint32_t)numSpawn : g < numSpawn) {
                 spawn_from_range(keyRs, gi, sh.bx, sh.by, sh.bz, sh.range, sh.stdRange, ox[m], oy[m], oz[m], ot[m]);
             } else if (ahead) {
                 spawn_from_other_n(nj[m < kAhead ? m : 0], ax[s][m], ay[s][m], az[s][m], at[s][m], kHxyz, hTheta, ox[m], oy[m], oz[m], ot[m]);
@@ -1448,8 +1570,37 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 7))
     }
 }
 
-// The same for one shard of a sharded filter (global indices, foreign offspring staged).  The host launches it
-// before it has looked at the previous decision, so that waiting for that decision overlaps with this kernel.
+// The same for one shard of a sharded filter, destination-owned like k_loc_deposit: workgroup d makes the shard's tile d
+// from the shard's own ancestors (plan records by k_loc_shard_decide_plan).  Tiles none of whose elements descend from a local
+// ancestor are left to k_loc_land; the offspring that belong to OTHER shards are staged by k_loc_stage_foreign.
+template <bool MOTION>
+#ifndef PF_SHARD_WAVES
+#define PF_SHARD_WAVES 7
+#endif
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PF_SHARD_WAVES, PF_SHARD_WAVES))) void k_loc_deposit_shard(LocBufs bufs, const LocCtl* __restrict__ ctl,
+                                                               double* __restrict__ tileSums,
+                                                               const double* __restrict__ chunkBase,
+                                                               const double* __restrict__ tileIncl, int numTiles, int n,
+                                                               long long idx0, RngKey keyRs, RespawnShell sh, RngKey key, Motion mo,
+                                                               Gate ga, const DestPlan* __restrict__ plan)
+{
+    union DepositLds { DestLds dest; double red[7 * kThreads]; };
+    __shared__ DepositLds L;
+    const int d = blockIdx.x;
+    const DestPlan P = plan[d];
+    if (ctl->branch == 1) {
+        const long long first = ctl->selfBegin + (long long)d * kTile;      // global index of the tile's first element
+        if (first >= ctl->outEnd || first + kTile <= ctl->outBegin) return;
+        resample_dest_tile<1, true, MOTION, false, false, true>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga,
+                                                                tileSums, nullptr, nullptr, P, L.dest);
+    } else {
+        stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, idx0, key, mo, ga, L.red, d);
+    }
+}
+
+// The source-owned form (round 1; PFX_SHARD_DIRECT=0): a workgroup owns a SOURCE tile (global indices, foreign offspring
+// staged).  The host launches it before it has looked at the previous decision, so that waiting for that decision
+// overlaps with this kernel.
 template <bool MOTION>
 __global__ __launch_bounds__(kThreads) void k_loc_deposit_sharded(LocBufs bufs, const LocCtl* __restrict__ ctl,
                                                                  double* __restrict__ tileSums,
@@ -1460,9 +1611,48 @@ __global__ __launch_bounds__(kThreads) void k_loc_deposit_sharded(LocBufs bufs, 
 {
     __shared__ ResampleDepositLds L;
     if (ctl->branch == 1)
-        resample_deposit_tile<MOTION, true>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga, out, stage, L);
+        resample_deposit_tile<MOTION, true>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga, out, stage, L,
+                                            (int)blockIdx.x);
     else
         stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, idx0, key, mo, ga, reinterpret_cast<double*>(&L), (int)blockIdx.x);
+}
+
+// The offspring of this shard's ancestors that belong to OTHER shards (global index outside [selfBegin, selfEnd)), as
+// records in the send half of the staging area: the companion of k_loc_deposit_shard.  They descend from the shard's
+// first and last source tiles (those whose CDF span reaches below position u(selfBegin) or beyond u(selfEnd)): every
+// thread tests one tile with two comparisons, the few tiles that pass are taken one after the other by the whole
+// workgroup, source-owned (resample_deposit_tile<STAGE_ONLY>: tile in LDS, its foreign offspring in a strided loop).
+// Grid: one workgroup per 256 tiles.
+__global__ __launch_bounds__(kThreads) void k_loc_stage_foreign(LocBufs bufs, const LocCtl* __restrict__ ctl,
+                                                               const double* __restrict__ chunkBase,
+                                                               const double* __restrict__ tileIncl, int numTiles, int n,
+                                                               RngKey keyRs, RespawnShell sh, StagePtrs stage)
+{
+    if (ctl->branch != 1) return;
+    __shared__ ResampleDepositLds L;
+    __shared__ int list[kThreads];
+    __shared__ int count;
+    const int tid = threadIdx.x, t = blockIdx.x * kThreads + tid;
+    if (tid == 0) count = 0;
+    __syncthreads();
+    const long long gOff = ctl->selfBegin, selfEnd = gOff + n, outBegin = ctl->outBegin, outEnd = ctl->outEnd;
+    const bool below = outBegin < gOff, above = outEnd > selfEnd;
+    if (t < numTiles && (below || above)) {
+        const double rStart = ctl->rStart, rStep = ctl->rStep, shardBase = ctl->shardBase, shardEnd = ctl->shardEnd;
+        const double a = tile_start_cdf(chunkBase, tileIncl, t, shardBase, shardEnd);
+        const double b = tile_start_cdf(chunkBase, tileIncl, t + 1, shardBase, shardEnd);
+        // offspring i of the tile: a <= u_i < b, u non-decreasing in i.  (Written so that a NaN position keeps the tile.)
+        bool need = (below && !(a > rStart + rStep * (double)gOff)) || (above && !(b <= rStart + rStep * (double)selfEnd));
+        need = need || (below && t == 0) || (above && t == numTiles - 1);   // the shard's ends are what the global plan says
+        if (need) list[atomicAdd(&count, 1)] = t;
+    }
+    __syncthreads();
+    const int c = count;
+    for (int q = 0; q < c; ++q) {
+        if (q > 0) __syncthreads();
+        resample_deposit_tile<false, true, true>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, keyRs, Motion{}, Gate{},
+                                                 PieceOut{ nullptr, nullptr, nullptr }, stage, L, list[q]);
+    }
 }
 
 // Offspring received from the neighbouring shards: record k of `landing` belongs to local element k (k < lo: sent by

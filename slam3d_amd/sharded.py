@@ -135,6 +135,10 @@ class GpuShard:
         """the O(N) pass; acts on the previous decision on the device (resample-and-deposit, or stream)"""
         self._lib.check(self._L.pfx_loc_shard_deposit(self._h), "pfx_loc_shard_deposit")
 
+    def stage(self):
+        """after a fused deposit whose plan sends offspring to other shards: produce them into the staging area"""
+        self._lib.check(self._L.pfx_loc_shard_stage(self._h), "pfx_loc_shard_stage")
+
     def local_sums(self):
         return self._local
 
@@ -298,6 +302,8 @@ class ShardedLocFilter:
         sends, recvs, _below = exchange_plan(F, T, r)
         lo = min(max(F[r], T[r]), T[r + 1]) - T[r]              # the local elements [lo, hi) were produced here
         hi = max(max(min(F[r + 1], T[r + 1]), T[r]) - T[r], lo)
+        if deposit and sends:
+            sh.stage()                          # (without a deposit, produce() has staged them already)
         # record k of the landing area: local element k (k < lo) or hi + (k - lo)
         self._p2p([(p, sh.stage_view(off, cnt)) for p, off, cnt in sends],
                   [(p, sh.landing_view(off if off < lo else lo + (off - hi), cnt)) for p, off, cnt in recvs])

@@ -104,6 +104,9 @@ class OracleShard:
             self._outstanding = False
             self.stream()
 
+    def stage(self):
+        """the device library produces the foreign offspring of a fused deposit here; _resample() has staged them already"""
+
     def stream(self):
         """VIO motion + gate over all local particles and the 8 local sums"""
         bx, by, bz, rng, std = self._args

@@ -55,6 +55,11 @@ class InProcessShards:
             lo = min(max(F[g], self.T[g]), self.T[g + 1]) - self.T[g]
             hi = max(max(min(F[g + 1], self.T[g + 1]), self.T[g]) - self.T[g], lo)
             ranges.append((lo, hi))
+            if deposit and sends:
+                sh.stage()
+        self.torch.cuda.synchronize()
+        for g, sh in enumerate(self.shards):
+            sends, recvs, _ = exchange_plan(F, self.T, g)
             for peer, off, cnt in sends:
                 # where the peer expects it: its own recv entry for this sender
                 psends, precvs, _ = exchange_plan(F, self.T, peer)
@@ -134,10 +139,16 @@ def _compare(got, ref, n, tol=1e-6):
         assert d.max() <= 4 * tol, (k, float(d.max()))
 
 
-@pytest.mark.parametrize("world,n,pose_every", [(1, 50000, 3), (2, 50001, 1), (4, 100003, 4), (7, 200000, 5), (16, 70000, 2)])
-def test_in_process_shards_match_unsharded(world, n, pose_every):
+@pytest.mark.parametrize("direct", ["1", "0"], ids=["destination-owned", "source-owned"])
+@pytest.mark.parametrize("world,n,pose_every", [(1, 50000, 3), (2, 50001, 1), (4, 100003, 4), (7, 200000, 5), (16, 70000, 2),
+                                                (2, 700001, 4), (3, 1500007, 6)])
+def test_in_process_shards_match_unsharded(world, n, pose_every, direct, monkeypatch):
+    """direct: the fused pass of a shard is destination-owned (k_loc_deposit_shard + k_loc_stage_foreign, plan records by
+    k_loc_shard_plan; the default) or source-owned (round 1's k_loc_deposit_sharded, PFX_SHARD_DIRECT=0, read when a shard is
+    configured).  The two largest cases have shards of more than one chunk of 256 tiles."""
     from slam3d_amd import particlefilter as pfm
     import sharded_worker as W
+    monkeypatch.setenv("PFX_SHARD_DIRECT", direct)
     ev = W.events(16)
     g = pfm.DeviceParticleFilterLoc(n, seed=SEED)
     ref_branches = []
