@@ -470,7 +470,10 @@ extern "C" pfx_loc* pfx_loc_create(int64_t n, uint32_t seed, uint32_t stream_id,
     pf->device = device;
     pf->n = n;
     pf->numTiles = (int)((n + kTile - 1) / kTile);
-    pf->padded = (size_t)pf->numTiles * kTile;
+    // The ten particle arrays lie `padded` floats apart.  An odd number of 4 KB tiles: with an even one -- N = 2^24, where the
+    // arrays are exactly 64 MiB apart -- the five streams of a pass walk the same memory channels in step, and the streaming
+    // passes run 5-6 % slower (measured at N = 2^24: 0.1072 -> 0.1011 ms with motion, 0.0879 -> 0.0835 without).
+    pf->padded = (size_t)(pf->numTiles | 1) * kTile;
     pf->numChunks = (pf->numTiles + kChunkTiles - 1) / kChunkTiles;
     pf->seed = seed;
     pf->streamId = stream_id;
