@@ -1241,6 +1241,20 @@ __device__ __forceinline__ int find_source_tile(const double* __restrict__ chunk
 #define PF_NOISE_AHEAD2 1
 #endif
 constexpr int kDepositTiles = PF_DEPOSIT_TILES;     // destination tiles per workgroup of k_loc_deposit
+#ifndef PF_XCD_REMAP
+#define PF_XCD_REMAP 0
+#endif
+// Workgroups are dealt to the eight XCDs round robin (workgroup b runs on XCD b % 8), each XCD has an L2 of its own.  With
+// tile = workgroup index, neighbouring destination tiles -- which draw from the same source tiles -- run on different
+// XCDs and every L2 fetches those source tiles for itself.  This deals each XCD a contiguous eighth of the tiles instead.
+// Measured (-DPF_XCD_REMAP=1, same box, N = 16 M): WORSE -- resampling side 0.149 -> 0.164 ms, static streaming side
+// 0.078 -> 0.081: eight distant regions of ten arrays each are open at once instead of one (address translation reach,
+// presumably), and that costs more than the shared source tiles save.  Off.
+__device__ __forceinline__ int xcd_tile(int b, int numTiles)
+{
+    const int x = b & 7, idx = b >> 3, per = numTiles >> 3, rem = numTiles & 7;
+    return x * per + (x < rem ? x : rem) + idx;
+}
 struct DestLds {
     double tab[kTile];          // CDF of the source tile at hand (integer form: the first half)
     double park[7 * 64];
@@ -1261,9 +1275,9 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
                                                    int numTiles, int n, const RngKey& keyRs, const RespawnShell& sh,
                                                    const RngKey& key, const Motion& mo, const Gate& ga,
                                                    double* __restrict__ tileSums, int* __restrict__ ancOut,
-                                                   double* __restrict__ rsPart, const DestPlan& P, DestLds& L)
+                                                   double* __restrict__ rsPart, const DestPlan& P, DestLds& L, int d0)
 {
-    const int d0 = blockIdx.x * NSUB, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int src = ctl->src, dst = ctl->dst;
     const double rStart = ctl->rStart, rStep = ctl->rStep, S = ctl->S;
     const float hTheta = ctl->htheta;
@@ -1530,7 +1544,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample_dest(LocBufs bufs, Lo
     __shared__ DestLds L;
     if (POSE && blockIdx.x == 0 && threadIdx.x == 0) ctl->rsValid = 1;  // nobody in this launch reads it; k_loc_pose_tiles then exits
     resample_dest_tile<1, false, false, RECORD, POSE>(bufs, ctl, chunkBase, tileIncl, numTiles, n, key, sh, key, Motion{}, Gate{},
-                                                   nullptr, ancOut, rsPart, P, L);
+                                                   nullptr, ancOut, rsPart, P, L, (int)blockIdx.x);
 }
 
 // One deposit of an unsharded filter with deferred resampling, whichever way the previous decision went (it is
@@ -1556,12 +1570,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 7))
 {
     union DepositLds { DestLds dest; double red[7 * kThreads]; };
     __shared__ DepositLds L;
+#if PF_XCD_REMAP
+    static_assert(kDepositTiles == 1, "the remap deals single tiles");
+    const int d0 = xcd_tile(blockIdx.x, numTiles);
+#else
     const int d0 = blockIdx.x * kDepositTiles;
+#endif
     const DestPlan P = plan[d0];            // read together with the control block: one round trip (unused when streaming)
     const int branch = ctl->branch;
     if (branch == 1) {
         resample_dest_tile<kDepositTiles, true, MOTION, false, false>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga,
-                                                                      tileSums, nullptr, nullptr, P, L.dest);
+                                                                      tileSums, nullptr, nullptr, P, L.dest, d0);
     } else {
         for (int s = 0; s < kDepositTiles && d0 + s < numTiles; ++s) {
             if (s > 0) __syncthreads();     // the previous tile's last reads of L.red
@@ -1592,7 +1611,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PF_SHA
         const long long first = ctl->selfBegin + (long long)d * kTile;      // global index of the tile's first element
         if (first >= ctl->outEnd || first + kTile <= ctl->outBegin) return;
         resample_dest_tile<1, true, MOTION, false, false, true>(bufs, ctl, chunkBase, tileIncl, numTiles, n, keyRs, sh, key, mo, ga,
-                                                                tileSums, nullptr, nullptr, P, L.dest);
+                                                                tileSums, nullptr, nullptr, P, L.dest, d);
     } else {
         stream_tile<MOTION, true>(bufs, ctl, tileSums, (long long)n, idx0, key, mo, ga, L.red, d);
     }
