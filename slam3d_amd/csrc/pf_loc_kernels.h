@@ -1249,11 +1249,21 @@ constexpr int kDepositTiles = PF_DEPOSIT_TILES;     // destination tiles per wor
 // XCDs and every L2 fetches those source tiles for itself.  This deals each XCD a contiguous eighth of the tiles instead.
 // Measured (-DPF_XCD_REMAP=1, same box, N = 16 M): WORSE -- resampling side 0.149 -> 0.164 ms, static streaming side
 // 0.078 -> 0.081: eight distant regions of ten arrays each are open at once instead of one (address translation reach,
-// presumably), and that costs more than the shared source tiles save.  Off.
+// presumably), and that costs more than the shared source tiles save.  PF_XCD_REMAP=2 (eight consecutive tiles per XCD
+// inside every group of 64, so that all XCDs stay in one region): resampling side unchanged (0.152 / 0.152), streaming
+// sides +1.5 % / +4 % -- the memory likes the tiles in plain order.  Off.
 __device__ __forceinline__ int xcd_tile(int b, int numTiles)
 {
+#if PF_XCD_REMAP == 2
+    // inside every group of 64 tiles XCD x takes the eight consecutive tiles 8 x .. 8 x + 7: neighbours share an L2, and all
+    // XCDs stay in the same region of the arrays
+    const int g = b & ~63;
+    if (g + 64 > numTiles) return b;
+    return g + ((b & 7) << 3) + ((b >> 3) & 7);
+#else
     const int x = b & 7, idx = b >> 3, per = numTiles >> 3, rem = numTiles & 7;
     return x * per + (x < rem ? x : rem) + idx;
+#endif
 }
 struct DestLds {
     double tab[kTile];          // CDF of the source tile at hand (integer form: the first half)
