@@ -589,8 +589,8 @@ def _random_ragged(n, seed):
     return w
 
 
-@pytest.mark.parametrize("n", [1, 3, 1023, 1024, 1025, 2048, 4096 + 5, 10 * 1024, 23 * 1024 + 1000, 256 * 1024 + 1,
-                               700 * 1024 + 77])
+@pytest.mark.parametrize("n", [1, 3, 1023, 1024, 1025, 2048, 4096 + 5, 10 * 1024, 23 * 1024 + 1000, 256 * 1024 - 1, 256 * 1024,
+                               256 * 1024 + 1, 257 * 1024, 512 * 1024, 512 * 1024 + 1025, 700 * 1024 + 77])
 def test_resample_random_ragged_weights(pfm, ora, n):
     """Five random ragged weight sets per size, sizes around the tile boundaries: recorded ancestors equal the oracle's,
     and the production pair (resampling on its own / fused into the next deposit) leaves bit-identical particles."""
