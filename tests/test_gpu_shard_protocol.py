@@ -209,12 +209,14 @@ def test_sharded_kernels_against_the_oracle(ora, world):
         assert s.moved > 0
 
 
-def test_concentrated_weight_one_shard_feeds_all():
+@pytest.mark.parametrize("n", [40000, 1200003])
+def test_concentrated_weight_one_shard_feeds_all(n):
     """All the weight sits in shard 1 of 4: it produces every offspring, three quarters of them foreign (staged below
     and above its own range); the other shards produce nothing and receive everything.  With slack 3.0 the staging
-    areas hold it.  Run once with the resampling materialised by a pose query and once fused into the next deposit."""
+    areas hold it.  Run once with the resampling materialised by a pose query and once fused into the next deposit.
+    (The larger size: shards of more than one chunk of 256 tiles.)"""
     from slam3d_amd import particlefilter as pfm
-    n, world = 40000, 4
+    world = 4
     rs = np.random.RandomState(3)
     x, y, z = (rs.uniform(-3, 3, n).astype(np.float32) for _ in range(3))
     th = rs.uniform(0, 6.28, n).astype(np.float32)
