@@ -663,39 +663,48 @@ __global__ __launch_bounds__(kDecideMapThreads) void k_loc_shard_decide_plan(Loc
     __shared__ double decD[6];          // resample, rStart, rStep, S, shardBase, shardEnd
     __shared__ long long decL[2];       // outBegin, outEnd
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        double tot[7] = { 0, 0, 0, 0, 0, 0, 0 };
-        double gb[kMaxShards + 1];
-        gb[0] = 0.0;
-        for (int g = 0; g < numShards; ++g) {
+    if (tid < 64) {
+        // every lane of the first wavefront takes the decision (uniform loads, the same arithmetic); lane g then works out
+        // where shard g's offspring begin -- up to seventeen float64 divisions side by side instead of in a row
+        // lane g loads shard g's sums (one round trip for all of them); the totals are then added up shard by shard, in
+        // rank order as k_loc_shard_decide does, every lane the same additions; lane g keeps the prefix in front of shard g
+        double mine[7], tot[7] = { 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
-            for (int k = 0; k < 7; ++k) tot[k] += all[g * 8 + k];
-            gb[g + 1] = tot[0];                     // sequential prefix: non-decreasing, gb[G] == S exactly
+        for (int k = 0; k < 7; ++k) mine[k] = tid < numShards ? all[tid * 8 + k] : 0.0;
+        double myBase = 0.0;                        // start of shard g's span of the global CDF (the total for lane G)
+#pragma unroll 1
+        for (int q = 0; q < numShards; ++q) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) tot[k] += __shfl(mine[k], q, 64);
+            if (tid == q + 1) myBase = tot[0];      // sequential prefix: non-decreasing, the last one == S exactly
         }
         const Decision d = decide_compute(tot, nGlobal, range, decide_uniform(key), force);
-        auto first_of = [&](int g) -> long long {
-            if (!d.resample) return 0;
-            return (g == 0) ? 0 : (g == numShards ? nGlobal : first_offspring_at(gb[g], d.rStart, d.rStep, nGlobal));
-        };
-        const long long ob = first_of(rank), oe = first_of(rank + 1);
-        decD[0] = d.resample ? 1.0 : 0.0; decD[1] = d.rStart; decD[2] = d.rStep; decD[3] = d.S;
-        decD[4] = gb[rank]; decD[5] = gb[rank + 1];
-        decL[0] = ob; decL[1] = oe;
+        const int g = tid <= numShards ? tid : numShards;
+        long long F = 0;
+        if (d.resample) F = (g == 0) ? 0 : (g == numShards ? nGlobal : first_offspring_at(myBase, d.rStart, d.rStep, nGlobal));
+        if (tid == rank) { decL[0] = F; decD[4] = myBase; }
+        if (tid == rank + 1) { decL[1] = F; decD[5] = myBase; }
+        if (tid == 0) { decD[0] = d.resample ? 1.0 : 0.0; decD[1] = d.rStart; decD[2] = d.rStep; decD[3] = d.S; }
         if (blockIdx.x == 0) {
-            decide_commit(ctl, d, branchLog);
-            if (!d.resample) {  // local part of the pose sums; the host all-reduces them when a pose is asked for
-                const double* l = ctl->local;
-                ctl->pose[0] = l[0]; ctl->pose[1] = l[4]; ctl->pose[2] = l[5]; ctl->pose[3] = l[6]; ctl->pose[4] = l[2]; ctl->pose[5] = l[3];
+            if (tid <= numShards) hostPlan->F[tid] = F;
+            const long long ob = __shfl(F, rank, 64), oe = __shfl(F, rank + 1, 64);
+            const double sb = __shfl(myBase, rank, 64), se = __shfl(myBase, rank + 1, 64);
+            if (tid == 0) {
+                decide_commit(ctl, d, branchLog);
+                if (!d.resample) {  // local part of the pose sums; the host all-reduces them when a pose is asked for
+                    const double* l = ctl->local;
+                    ctl->pose[0] = l[0]; ctl->pose[1] = l[4]; ctl->pose[2] = l[5]; ctl->pose[3] = l[6]; ctl->pose[4] = l[2]; ctl->pose[5] = l[3];
+                }
+                hostPlan->branch = d.resample ? 1 : 0;
+                hostPlan->numSpawn = d.numSpawn; hostPlan->htheta = d.htheta; hostPlan->wscale = d.resample ? 1.0f : d.m;
+                hostPlan->S = tot[0]; hostPlan->rStart = d.rStart; hostPlan->rStep = d.rStep;
+                ctl->shardBase = sb; ctl->shardEnd = se;
+                ctl->outBegin = ob; ctl->outEnd = oe;
+                ctl->selfBegin = selfBegin; ctl->selfEnd = selfEnd; ctl->nGlobal = nGlobal;
             }
-            hostPlan->branch = d.resample ? 1 : 0;
-            hostPlan->numSpawn = d.numSpawn; hostPlan->htheta = d.htheta; hostPlan->wscale = d.resample ? 1.0f : d.m;
-            hostPlan->S = tot[0]; hostPlan->rStart = d.rStart; hostPlan->rStep = d.rStep;
-            for (int g = 0; g <= numShards; ++g) hostPlan->F[g] = (g == rank) ? ob : (g == rank + 1) ? oe : first_of(g);
-            ctl->shardBase = gb[rank]; ctl->shardEnd = gb[rank + 1];
-            ctl->outBegin = ob; ctl->outEnd = oe;
-            ctl->selfBegin = selfBegin; ctl->selfEnd = selfEnd; ctl->nGlobal = nGlobal;
+            // the sequence number goes out after every lane's part of the plan (one wavefront: program order + the fence)
             __threadfence_system();
-            __hip_atomic_store(&hostPlan->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid == 0) __hip_atomic_store(&hostPlan->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     for (int c = tid; c <= numChunks; c += kDecideMapThreads) base[c] = chunkBase[c];
