@@ -720,7 +720,10 @@ __global__ __launch_bounds__(kDecideMapThreads) void k_loc_shard_decide_plan(Loc
 // N = 10 000: 33.4 -> 30.4 us per step of two deposits).  With four chunks (-DPF_SMALL_CHUNKS=4, N <= 1 M) it loses, also
 // with the plan records written from the source side: 36.7 -> 38.8 us per step at N = 500 000, 41.7 -> 58.1 at N = 1 M --
 // one workgroup takes the chunks one after the other (five barriers each) where the two kernels have a workgroup per
-// chunk.  Same functions on the same values in the same order as the two kernels: the results are bit-identical, the
+// chunk.  The step further -- k_loc_deposit and this kernel in one launch, the workgroup that arrives last (device-scope
+// fence, one atomic) taking the decision -- was measured too: 28.1 -> 28.7 us per step at N = 10 000 (the step is bound by the
+// host's calls there, not by the launches), 28.7 -> 31.1 at N = 100 000, 30.8 -> 40.0 at N = 262 144; dropped.
+// Same functions on the same values in the same order as the two kernels: the results are bit-identical, the
 // arrays they leave in global memory (tileIncl, chunkSums, chunkBase, plan) are those the big kernels expect; inside the
 // kernel they travel through LDS.
 constexpr int kSmallChunks = PF_SMALL_CHUNKS;
