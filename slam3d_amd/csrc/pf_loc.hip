@@ -840,12 +840,14 @@ extern "C" int pfx_resample_indices_f64(const double* cdf, int64_t n, double rSt
 // deposit.  Sequence per deposit on every rank (include/pfx.h has the long form):
 //   pfx_loc_shard_begin(pf, beacon, range, std)   VIO commit; spawns on the first range (returns 1: nothing else follows)
 //   pfx_loc_shard_deposit(pf)                     the O(N) pass, launched without looking at the previous decision: after a
-//                                                 "resample" the offspring of the local ancestors are produced and deposited
-//                                                 on in the same pass (foreign ones staged as records), else the streaming pass
+//                                                 "resample" the offspring of the local ancestors that fall into the shard's
+//                                                 own range are produced and deposited on in the same pass, else the
+//                                                 streaming pass
 //   pfx_loc_shard_plan(pf, &branch, F)            the previous decision (it has landed in pinned memory meanwhile)
-//   after a "resample":  (records shipped to the owners' landing areas by the caller, e.g. RCCL send/recv)
+//   after a "resample":  pfx_loc_shard_stage(pf)               if F sends offspring elsewhere: they are staged as records
+//                        (records shipped to the owners' landing areas by the caller, e.g. RCCL send/recv)
 //                        pfx_loc_shard_land(pf, 1, lo, hi)     received records unpacked and deposited on
-//                        pfx_loc_shard_finish(pf, 1, lo, hi)   local prefix from the pieces
+//                        pfx_loc_shard_finish(pf, 1, lo, hi)   local prefix (sums of the received elements added in)
 //   after a "normalise": pfx_loc_shard_finish(pf, 0, 0, 0)
 //   (all-gather of the 8 local sums of every rank, pfx_loc_shard_local_ptr -> pfx_loc_shard_all_ptr, by the caller)
 //   pfx_loc_shard_decide(pf)                      the global decision, identical on every rank; a "resample" stays pending
