@@ -70,15 +70,20 @@ def scene(n_steps):
 POSE_EVERY_STEP = False     # --pose-every-step: the replay drivers' pattern (a getTagLoc per VIO row); not the headline metric
 
 
-def step(pf, k, bx, truth, rng):
-    """one STEP of the workload on any object with the wrapper interface"""
+def step(pf, k, bx, truth, rng, ranges_only=False):
+    """one STEP of the workload on any object with the wrapper interface.  ranges_only (extra.tracking): the second
+    deposit is a depositRange with the measured range to beacon (k+1)%8 instead of SURVEY's depositRssi, whose fixed
+    1.5 m +- 1.5 m contradicts every beacon of this scene -- the same two passes per step on a filter that tracks."""
     pf.depositVio(1000.0 + 0.1 * k, float(truth[k, 0]), float(truth[k, 1]), float(truth[k, 2]), 0.0)
     if POSE_EVERY_STEP:
         pf.getTagLoc()
     b = k % 8
     pf.depositRange(float(bx[b, 0]), float(bx[b, 1]), float(bx[b, 2]), float(rng[k, 0]), 0.1)
     b = (k + 1) % 8
-    pf.depositRssi(float(bx[b, 0]), float(bx[b, 1]), float(bx[b, 2]), -60)
+    if ranges_only:
+        pf.depositRange(float(bx[b, 0]), float(bx[b, 1]), float(bx[b, 2]), float(rng[k, 1]), 0.1)
+    else:
+        pf.depositRssi(float(bx[b, 0]), float(bx[b, 1]), float(bx[b, 2]), -60)
 
 
 # ------------------------------------------------------------------ CPU baselines (rank 0, N = 1 only)
@@ -132,6 +137,42 @@ def _in_big_stack_thread(fn, stack_mb):
     return out.get("r")
 
 
+def host_threads():
+    """(threads for the all-cores baseline, what the host offers).  Every CPU this process may run on: os.cpu_count(),
+    cut down to the scheduler affinity mask and to the cgroup CPU quota where the box sets one (a GPU box hands a
+    one-GPU job a share of its CPUs; threads beyond the quota would only take turns).  BENCH_CPU_THREADS overrides."""
+    avail = os.cpu_count() or 1
+    info = {"cores_available": avail}
+    n = avail
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+        n = min(n, info["affinity"])
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+        if q != "max":
+            info["cgroup_cpu_quota"] = float(q) / float(per)
+            n = min(n, max(1, int(info["cgroup_cpu_quota"] + 0.5)))
+    except (OSError, ValueError):
+        pass
+    if os.environ.get("BENCH_CPU_THREADS"):
+        n = int(os.environ["BENCH_CPU_THREADS"])
+        info["threads_from"] = "BENCH_CPU_THREADS"
+    return max(1, min(n, 1000)), info
+
+
+def kernel_sources_sha():
+    """what profiles/pmc_traffic.json was measured on (tools/pmc_traffic.py records it): the kernel sources"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pf_common.h", "pf_loc_kernels.h"):
+        with open(os.path.join(ROOT, "slam3d_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(budget_s=12.0):
     """The same workload on the host: the primary record is ONE core at N = 1 M (a bounded sample of the GPU workload);
     `variants` adds one core at the full N = 16 M and all host cores.  Prefers the compiled reference (kind
@@ -165,7 +206,7 @@ def cpu_baseline(budget_s=12.0):
     # with its own Philox stream -- what a threaded port of the reference could reach at best: the serial rand_r
     # stream cannot be split, and a real port would still have to join the threads for the global resampling
     from oracle import oracle as ora
-    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
+    cores, cores_info = host_threads()
     n_each = 16000000 // cores
     filters = [ora.OracleLoc(n_each, rng_mode=ora.RNG_PHILOX, seed=1000 + i, acc=ora.ACC_F32) for i in range(cores)]
     res = [None] * cores
@@ -184,7 +225,7 @@ def cpu_baseline(budget_s=12.0):
     variants.append({"value": upd / max(r[1] for r in res), "unit": "particle-updates/s", "cores": cores, "kind": "port",
                      "sample": f"{cores} threads x one oracle filter of N={n_each:,} each (16 M in all), {res[0][0]} steps, {wall:.1f} s wall "
                                "incl. spawn; per-thread Philox streams, float32 sums; upper bound of a threaded port (no join for "
-                               "the global resampling)", "cpu_model": cpu_model})
+                               "the global resampling)", "cpu_model": cpu_model, **cores_info})
     primary["variants"] = variants
     return primary
 
@@ -327,7 +368,7 @@ def measure_slam(F, B, K, W, world, rank, local, dist, torch, with_cpu=False, ce
 
 
 # ------------------------------------------------------------------ config 3: one Loc filter
-def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, headline, pre_roll=None):
+def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, headline, pre_roll=None, ranges_only=False):
     """pre_roll (default PRE_ROLL) + W untimed steps, K timed; returns (record fields, per-kernel table) on rank 0,
     (None, None) elsewhere"""
     PRE_ROLL = globals()["PRE_ROLL"] if pre_roll is None else pre_roll
@@ -352,7 +393,7 @@ def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, head
     pf.depositVio(999.9, float(truth[0, 0]), float(truth[0, 1]), float(truth[0, 2]), 0.0)
     pf.depositRange(float(bx[0, 0]), float(bx[0, 1]), float(bx[0, 2]), float(rng[0, 0]), 0.1)
     for k in range(PRE_ROLL + W):
-        step(pf, k, bx, truth, rng)
+        step(pf, k, bx, truth, rng, ranges_only)
     barrier()
 
     events = headline and not args.no_kernel_events
@@ -365,7 +406,7 @@ def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, head
     barrier()
     t0 = time.perf_counter()
     for k in range(PRE_ROLL + W, PRE_ROLL + W + K):
-        step(pf, k, bx, truth, rng)
+        step(pf, k, bx, truth, rng, ranges_only)
     barrier()
     dt = time.perf_counter() - t0
 
@@ -383,6 +424,12 @@ def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, head
         return None, None
     rec = {"value": 2.0 * n * world * K / dt, "ms_per_step": dt / K * 1e3, "particles_per_gpu": n, "steps": K,
            "resample_fraction": float(branches.mean()) if branches.shape[0] else None, "final_position_error_m": err}
+    # every timed deposit by what its launch did: deposit j follows decision j - 1 (device-side branch log); even j carry
+    # the VIO motion, odd j are static
+    if full_log.shape[0] >= 2 * K + 1:
+        prev = full_log[-(2 * K + 1):-1].astype(bool)
+        rec["launch_classes"] = {"resample_stream": int(prev[0::2].sum()), "stream": int((~prev[0::2]).sum()),
+                                 "resample_static": int(prev[1::2].sum()), "stream_static": int((~prev[1::2]).sum())}
     if not events:
         return rec, {}
     names = pfm.DeviceParticleFilterLoc.KINDS
@@ -500,7 +547,19 @@ def main():
 
     rec, per = measure_loc(pfm, torch, dist, world, rank, local, n, K, W, args.force_branch, args, headline=True)
 
+    # N > 1: the north star's other multi-GPU numbers ride on the same line (every rank takes part in measuring them)
+    multi = None
+    if world > 1 and not args.no_extras:
+        multi = multi_gpu_extras(pfm, torch, dist, world, rank, local, args)
+
     if rank == 0:
+        traffic_tab, traffic_stale = {}, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic_tab = json.load(fh)
+            src = traffic_tab.get("_source", {})
+            traffic_stale = src.get("kernel_sources_sha") != kernel_sources_sha()
         dominant = max(per, key=lambda k_: per[k_]["total_ms"]) if per else None
         roof = None
         if dominant:
@@ -508,16 +567,16 @@ def main():
             # HBM bytes of one launch from the PMC counters (two rocprofv3 passes of this command, tools/pmc_traffic.py;
             # measured at N = 16 M, per particle, scaled to this run's N)
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath) and world == 1:
-                with open(tpath) as fh:
-                    t = json.load(fh).get(dominant, {})
-                if "hbm_bytes_per_particle" in t:
-                    traffic = t["hbm_bytes_per_particle"] * n
-                    tsrc = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per particle at N = 16 M"
+            t = traffic_tab.get(dominant, {})
+            if "hbm_bytes_per_particle" in t:
+                traffic = t["hbm_bytes_per_particle"] * n
+                tsrc = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per particle at "
+                        "N = 16 M; a constant of the profile, not re-measured in this run")
             roof = {"bound": "hbm", "kernel": KERNEL_OF[dominant],
                     "variant": dominant, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": d["frac"], "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": d["avg_ms"],
+                    "frac": d["frac"], "traffic": traffic, "traffic_source": tsrc,
+                    "traffic_stale": traffic_stale,     # True: the kernel sources have changed since the PMC passes
+                    "avg_launch_ms": d["avg_ms"],
                     "launches": d["launches"], "alg_bytes_per_particle": d["alg_bytes_per_particle"]}
             if traffic:
                 roof["dram_GBs"] = traffic / (d["avg_ms"] * 1e-3) / 1e9      # what the kernel really moves per second
@@ -533,7 +592,7 @@ def main():
         extra = None
         if world == 1 and not args.no_extras and not force_sharded:
             extra = {"note": f"same scene and step as the headline, {PRE_ROLL} pre-roll + 10 warm-up steps, no per-kernel events",
-                     "n_sweep": [], "always_resample": None, "transient": None, "config5": None}
+                     "n_sweep": [], "always_resample": None, "transient": None, "tracking": None, "loc_batch": None, "config5": None}
             for nn, kk in ((1000000, 100), (1 << 24, 50), (1 << 26, 30)):
                 r, _ = measure_loc(pfm, torch, dist, 1, 0, local, nn, kk, 10, -1, args, headline=False)
                 extra["n_sweep"].append(r)
@@ -543,7 +602,16 @@ def main():
             r, _ = measure_loc(pfm, torch, dist, 1, 0, local, n, 20, 5, -1, args, headline=False, pre_roll=40)
             r["pre_roll_steps"] = 40
             extra["transient"] = r
+            r, _ = measure_loc(pfm, torch, dist, 1, 0, local, n, 50, 10, -1, args, headline=False, ranges_only=True)
+            r["note"] = ("the same step with the second deposit a depositRange on the measured range to beacon (k+1)%8 instead of "
+                         "SURVEY's depositRssi (a fixed 1.5 m +- 1.5 m, which no beacon of this scene is within): a filter that "
+                         "tracks -- see final_position_error_m -- and seldom resamples")
+            extra["tracking"] = r
+            if hasattr(pfm, "DeviceLocBatch"):
+                extra["loc_batch"] = [measure_loc_batch(pfm, torch, local, F, nn, kk) for F, nn, kk in ((1600, 10000, 200), (16, 1000000, 100))]
             extra["config5"] = measure_slam(512, 4, 60, 10, 1, 0, local, dist, torch, with_cpu=not args.no_cpu_baseline)
+        elif multi is not None:
+            extra = multi
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
@@ -555,6 +623,20 @@ def main():
                      "frac": step_gbs / (HBM_PEAK_GBS * world),
                      "note": "depositRange (44 B/particle) + depositRssi (28) + resample_fraction x 2 resamplings (40 each), "
                              "over ms_per_step: launch gaps, the two small kernels per deposit and fusion gains all included"}
+        # ... and in the bytes the launches really moved: PMC bytes per particle of each launch class (profiles/
+        # pmc_traffic.json) x the launches of that class the device-side branch log counted in the timed region
+        lc = rec.get("launch_classes")
+        if lc and all(("hbm_bytes_per_particle" in traffic_tab.get(c, {})) or lc[c] == 0 for c in lc):
+            real = sum(traffic_tab[c]["hbm_bytes_per_particle"] * cnt for c, cnt in lc.items() if cnt) / K
+            real_gbs = real * n * world / (rec["ms_per_step"] * 1e-3) / 1e9
+            step_roof["real_bytes_per_particle_step"] = real
+            step_roof["real_GBs"] = real_gbs
+            step_roof["real_frac"] = real_gbs / (HBM_PEAK_GBS * world)
+            step_roof["real_note"] = ("HBM bytes the step's launches moved (rocprofv3 PMC per launch class x the class counts of "
+                                      "this run), over ms_per_step; the fused launches never move the 44/28 B pass that the "
+                                      "SURVEY pricing above charges them for")
+            step_roof["traffic_stale"] = traffic_stale
+        err = rec["final_position_error_m"]
         out = {
             "metric": "particle-updates/sec (range update+resample) at N=16M",
             "value": rec["value"], "unit": "particle-updates/s",
@@ -565,15 +647,18 @@ def main():
                                    "+ depositRssi (2 deposits = 2N particle-updates)",
                        "particles_per_gpu": n, "particles_total": n * world,
                        "parallelism": "single GPU" if world == 1 else f"one filter sharded by particle range over {world} GPUs, "
-                                                                       "RCCL all-gather of per-GPU sums per deposit, neighbour "
+                                                                       "chunk sums exchanged per deposit, neighbour "
                                                                        "send/recv of migrating offspring per resampling",
                        "force_branch": args.force_branch, "resample_fraction": rec["resample_fraction"],
+                       "launch_classes": lc,
                        "deferred_resampling": not args.undeferred or world > 1 or force_sharded,
                        "pose_every_step": POSE_EVERY_STEP, "pre_roll_steps": PRE_ROLL,
-                       "rng": "Philox4x32-10 key 123456789", "final_position_error_m": rec["final_position_error_m"],
+                       "rng": "Philox4x32-10 key 123456789", "final_position_error_m": err,
                        "scene_note": "SURVEY's config-3 scene is self-contradictory on purpose of traffic: every depositRssi asserts "
                                      "1.5 +- 1.5 m to a beacon >= 5 m from the truth, so each one gates the whole cloud and forces "
-                                     "the 5 % respawn; the estimate sits ~1 m off the truth and half the deposits resample"},
+                                     f"the 5 % respawn around that beacon; the filter does NOT track (estimate {err:.1f} m from the "
+                                     "truth at the end of this run) and about half the deposits resample.  A traffic case; "
+                                     "extra.tracking is the same step on ranges only, where the filter tracks"},
             "roofline": roof, "step_roofline": step_roof, "kernels": per, "cpu_baseline": cpu, "extra": extra,
         }
         emit(out)
@@ -581,6 +666,72 @@ def main():
         if world > 1:
             dist.barrier()
         dist.destroy_process_group()
+
+
+def multi_gpu_extras(pfm, torch, dist, world, rank, local, args):
+    """world > 1: BASELINE config 4 (ONE filter of 67 108 864 particles over all ranks, strong scaling, against the same
+    filter unsharded on rank 0's GPU, measured in this job while the other ranks wait) and config 5 (512 SLAM tags per
+    GPU, no communication).  Returns the `extra` object on rank 0."""
+    total = 1 << 26
+    out = {"note": "measured in the same job after the headline; every rank takes part", "config4": None, "config5": None}
+    single = None
+    if rank == 0:
+        single, _ = measure_loc(pfm, torch, dist, 1, 0, local, total, 30, 10, args.force_branch, args, headline=False)
+    dist.barrier()
+    r, _ = measure_loc(pfm, torch, dist, world, rank, local, total // world, 50, 10, args.force_branch, args, headline=False)
+    if rank == 0:
+        r.update({"scaling": "strong", "particles_total": (total // world) * world, "n_gpus": world,
+                  "single_gpu_ms_per_step": single["ms_per_step"], "single_gpu_value": single["value"],
+                  "speedup_vs_single_gpu": single["ms_per_step"] / r["ms_per_step"],
+                  "note": "BASELINE config 4: one particleFilterLoc of 2^26 particles sharded by particle range; the single-GPU "
+                          "figure is the unsharded filter of the same size on rank 0's GPU, same scene, same job"})
+        out["config4"] = r
+    dist.barrier()
+    c5 = measure_slam(args.slam_filters, args.slam_bcns, 60, 10, world, rank, local, dist, torch, with_cpu=False)
+    if rank == 0:
+        out["config5"] = c5
+    return out if rank == 0 else None
+
+
+def measure_loc_batch(pfm, torch, local, F, n, K, W=20):
+    """Many independent Loc filters in one set of launches ("also many Loc tags"): F filters of n
+    particles each, every filter its own scene phase; one STEP = depositVio + depositRange + depositRssi on every filter
+    (2 F n particle-updates), through pfx_loc_batch_*."""
+    bx, truth, rng = scene(PRE_ROLL + K + W + F + 1)
+    batch = pfm.DeviceLocBatch(F, n, seed=123456789, device=local)
+    off = np.arange(F) % 64                   # filter f runs the scene from step off[f] on: the tags are not in lockstep
+
+    def one(k):
+        kk = k + off
+        batch.deposit_vio(np.full(F, 1000.0 + 0.1 * k), truth[kk, 0], truth[kk, 1], truth[kk, 2], np.zeros(F, dtype=np.float32))
+        b = kk % 8
+        batch.deposit_range(bx[b, 0], bx[b, 1], bx[b, 2], rng[kk, 0], np.full(F, 0.1, dtype=np.float32))
+        b = (kk + 1) % 8
+        batch.deposit_rssi(bx[b, 0], bx[b, 1], bx[b, 2])
+
+    batch.deposit_vio(np.full(F, 999.9), truth[off, 0], truth[off, 1], truth[off, 2], np.zeros(F, dtype=np.float32))
+    batch.deposit_range(bx[off % 8, 0], bx[off % 8, 1], bx[off % 8, 2], rng[off, 0], np.full(F, 0.1, dtype=np.float32))
+    pre = min(PRE_ROLL, 100)
+    for k in range(pre + W):
+        one(k)
+    batch.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(pre + W, pre + W + K):
+        one(k)
+    batch.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    poses = batch.get_tag_loc()
+    err = np.linalg.norm(np.stack([poses[2], poses[3], poses[4]], axis=1).astype(np.float64) - truth[pre + W + K - 1 + off], axis=1)
+    step_bytes = 44 + 28 + 40 * 2 * batch.resample_fraction(2 * K)
+    gbs = step_bytes * n * F / (dt / K) / 1e9
+    return {"filters": F, "particles_per_filter": n, "value": 2.0 * n * F * K / dt, "unit": "particle-updates/s", "steps": K,
+            "ms_per_step": dt / K * 1e3, "us_per_filter_step": dt / K / F * 1e6,
+            "resample_fraction": batch.resample_fraction(2 * K), "median_position_error_m": float(np.median(err)),
+            "step_roofline_frac": gbs / HBM_PEAK_GBS,
+            "note": "pfx_loc_batch_*: F independent particleFilterLoc filters of equal N, one set of launches per deposit of the "
+                    "whole batch (grid dimension = filter), per-filter Philox stream, per-filter decision on the device"}
 
 
 if __name__ == "__main__":

@@ -79,6 +79,11 @@ int      pfx_loc_deposit_rssi(pfx_loc* pf, float bx, float by, float bz, int rss
 int      pfx_loc_get_tag_loc(pfx_loc* pf, double* t, float* x, float* y, float* z, float* theta);  /* 1 ok, 0 not initialised, <0 error */
 
 /* ---- state access ---- */
+/* Weights enter the weight total, the CDF and the pose sums rounded to multiples of 2^-20: exact sums in
+ * any order, sized for the path's own convention of mean weight 1 (pfResample.c:80-82); a weight below 2^-21 counts as 0.
+ * pfx_loc_upload therefore rescales a set whose mean weight lies below 2^-12, or whose total reaches 2^33, to mean 1 (factor N / sum w, what
+ * the reference's normalisation would apply at the next non-resampling deposit), and pfx_loc_download returns the
+ * rescaled weights; other sets are stored as given. */
 int      pfx_loc_upload(pfx_loc* pf, const float* w, const float* x, const float* y, const float* z,
                         const float* theta, int64_t n, int initialized);
 int      pfx_loc_download(pfx_loc* pf, float* w, float* x, float* y, float* z, float* theta, int64_t n);
@@ -123,6 +128,41 @@ int64_t  pfx_loc_profile_records(pfx_loc* pf, int32_t* kind, float* ms, int64_t 
 /* branch taken by each deposit since creation (1 resampled, 0 normalised), oldest first, at most the
  * last 65536; *total = number of decisions so far.  Synchronises the stream. */
 int64_t  pfx_loc_branch_log(pfx_loc* pf, uint8_t* out, int64_t cap, int64_t* total);
+
+/* ---- many Loc filters of equal size in one set of launches (no counterpart in the reference) ----
+ * The reference runs one filter per tag and one call per measurement (csvlocalize.c:64-88) at N = 10 000
+ * (particleFilter.h:18), a size at which a GPU deposit is bound by its launches and by the caller.  A pfx_loc_batch holds
+ * num_filters independent particleFilterLoc filters of n particles each on one GPU; every call below does for each filter
+ * f with mask[f] != 0 (mask NULL: every filter) exactly what the pfx_loc_* call of the same name does for one filter --
+ * same arithmetic, same deferred resampling, decisions taken per filter on the device -- in ONE set of kernel launches
+ * (grid dimension = filter).  Filter f draws its noise from Philox key (seeds[f] or seed0, stream_ids[f] or f): after
+ * the same calls it holds bit for bit the particles of pfx_loc_create(n, that seed, that stream id, device).  All arrays
+ * are host arrays of num_filters entries.  ("batch of independent filters ... also many Loc tags".) */
+typedef struct pfx_loc_batch pfx_loc_batch;
+pfx_loc_batch* pfx_loc_batch_create(int num_filters, int64_t n, const uint32_t* seeds, uint32_t seed0, const uint32_t* stream_ids, int device);
+void     pfx_loc_batch_destroy(pfx_loc_batch* b);
+int      pfx_loc_batch_num_filters(const pfx_loc_batch* b);
+int64_t  pfx_loc_batch_n(const pfx_loc_batch* b);
+uint32_t pfx_loc_batch_seed(const pfx_loc_batch* b, int f);
+uint32_t pfx_loc_batch_stream_id(const pfx_loc_batch* b, int f);
+uint32_t pfx_loc_batch_epoch(const pfx_loc_batch* b, int f);
+int      pfx_loc_batch_initialized(const pfx_loc_batch* b, int f);
+int      pfx_loc_batch_sync(pfx_loc_batch* b);
+int      pfx_loc_batch_set_force_branch(pfx_loc_batch* b, int force);          /* as pfx_loc_set_force_branch, whole batch */
+/* particleFilter.c:70-104 / 178-191 / 213-226 / 248-291 for every selected filter */
+int      pfx_loc_batch_deposit_vio(pfx_loc_batch* b, const uint8_t* mask, const double* t, const float* x, const float* y,
+                                   const float* z, const float* dist /* NULL: zeros */);
+int      pfx_loc_batch_deposit_range(pfx_loc_batch* b, const uint8_t* mask, const float* bx, const float* by, const float* bz,
+                                     const float* range, const float* stdRange);
+int      pfx_loc_batch_deposit_rssi(pfx_loc_batch* b, const uint8_t* mask, const float* bx, const float* by, const float* bz,
+                                    const int32_t* rssi /* unused, as in the reference; may be NULL */);
+int      pfx_loc_batch_get_tag_loc(pfx_loc_batch* b, uint8_t* ok, double* t, float* x, float* y, float* z, float* theta);
+/* state and diagnostics of one filter of the batch (as pfx_loc_download / pfx_loc_last_stats) */
+int      pfx_loc_batch_download(pfx_loc_batch* b, int f, float* w, float* x, float* y, float* z, float* theta, int64_t n);
+int      pfx_loc_batch_last_stats(pfx_loc_batch* b, int f, double out[12]);
+/* deposits decided / of those resampled since creation: batch totals, and per filter where the arrays are not NULL */
+int      pfx_loc_batch_branch_counts(pfx_loc_batch* b, int64_t* decisions, int64_t* resampled, int64_t* per_filter_decisions,
+                                     int64_t* per_filter_resampled);
 
 /* ---- one filter sharded by particle range over several GPUs (no counterpart in the reference) ----
  * The caller owns the collectives (slam3d_amd/sharded.py uses torch.distributed = RCCL); these are the local
@@ -180,7 +220,8 @@ int      pfx_loc_pose_from_sums(pfx_loc* pf, const double sums[6], double* t, fl
  * that cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation:
  * the pose reduction of getTagLoc (particleFilter.c:263-273; the kernels' code behind pfx_loc_shard_pose_sums) over the
  * caller's own DEVICE arrays w, x, y, z, theta of n particles (16-byte aligned; true weight = w * wscale, as
- * pfx_loc_device_arrays hands them out), six sums {w, w x, w y, w z, w cos theta, w sin theta} written to the caller's
+ * pfx_loc_device_arrays hands them out; w * wscale enters sum w rounded to a multiple of 2^-20, so pass a wscale that
+ * brings the mean weight to about 1 -- N for a set normalised to sum 1 -- or the total comes out 0), six sums {w, w x, w y, w z, w cos theta, w sin theta} written to the caller's
  * device buffer d_out6 by kernels enqueued on hip_stream (NULL = the default stream); feed them to pfx_loc_pose_from_sums.
  * The per-tile partial sums, for which a filter allocates a buffer of its own, live in a static device array of the
  * library: 4 MiB per GPU, held until the process ends, n <= 2^26 (larger n is refused with an error, nothing runs).

@@ -113,6 +113,30 @@ def lib() -> C.CDLL:
     sig("particleFilterLoc_depositRange", None, vp, f, f, f, f, f)
     sig("particleFilterLoc_depositRssi", None, vp, f, f, f, i)
     sig("particleFilterLoc_getTagLoc", C.c_uint8, vp, pd_, pf_, pf_, pf_, pf_)
+    # many Loc filters in one set of launches (pfx_loc_batch_*)
+    sig("pfx_loc_batch_create", vp, i, i64, vp, u32, vp, i)
+    sig("pfx_loc_batch_destroy", None, vp)
+    sig("pfx_loc_batch_num_filters", i, vp)
+    sig("pfx_loc_batch_n", i64, vp)
+    sig("pfx_loc_batch_seed", u32, vp, i)
+    sig("pfx_loc_batch_stream_id", u32, vp, i)
+    sig("pfx_loc_batch_epoch", u32, vp, i)
+    sig("pfx_loc_batch_initialized", i, vp, i)
+    sig("pfx_loc_batch_sync", i, vp)
+    sig("pfx_loc_batch_set_force_branch", i, vp, i)
+    sig("pfx_loc_batch_deposit_vio", i, vp, vp, vp, vp, vp, vp, vp)
+    sig("pfx_loc_batch_deposit_range", i, vp, vp, vp, vp, vp, vp, vp)
+    sig("pfx_loc_batch_deposit_rssi", i, vp, vp, vp, vp, vp, vp)
+    sig("pfx_loc_batch_get_tag_loc", i, vp, vp, vp, vp, vp, vp, vp)
+    sig("pfx_loc_batch_download", i, vp, i, vp, vp, vp, vp, vp, i64)
+    sig("pfx_loc_batch_last_stats", i, vp, i, pd_)
+    sig("pfx_loc_batch_branch_counts", i, vp, C.POINTER(i64), C.POINTER(i64), vp, vp)
+    # the Loc stage functions of the reference's internal headers (include/pfStages.h)
+    sig("pfRandom_init", None)
+    sig("pfInit_initTagLoc", None, vp, f, f, f, f, f)
+    sig("pfMeasurement_applyVioLoc", None, vp, f, f, f, f, f)
+    sig("pfMeasurement_applyRangeLoc", None, vp, f, f, f, f, f)
+    sig("pfResample_resampleLoc", None, vp, f, f, f, f, f)
     # batched SLAM filters (pfx_slam_*)
     u8p = C.POINTER(C.c_uint8)
     sig("pfx_slam_create", vp, i, i, i, i, vp, u32, i)

@@ -7,12 +7,14 @@
 // which has no way to report an error).
 #include "pf_loc_kernels.h"
 #include "pf_host.h"
+#include "pf_loc_host.h"
 
 #include "../../include/pfx.h"
 #include "../../include/pfStages.h"
 
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -43,7 +45,7 @@ void die(const char* what)
     abort();
 }
 static int g_abortOnError = 1;
-static long long g_errorCount = 0;
+static std::atomic<long long> g_errorCount{0};
 void fail(const char* what)
 {
     if (g_abortOnError) die(what);
@@ -53,7 +55,7 @@ void fail(const char* what)
 }  // namespace pf
 
 extern "C" void pfx_set_abort_on_error(int enable) { pf::g_abortOnError = enable ? 1 : 0; }
-extern "C" long long pfx_error_count(void) { return pf::g_errorCount; }
+extern "C" long long pfx_error_count(void) { return pf::g_errorCount.load(); }
 
 extern "C" {
 unsigned int PF_SEED = 0;       // pfRandom.c:51-52
@@ -61,36 +63,6 @@ int PF_SEED_SET = 0;
 }
 
 // ------------------------------------------------------------------ the filter object
-struct VioState {               // particleFilter.h:52-62 without the `initialized` byte
-    double firstT = 0.0; float firstX = 0, firstY = 0, firstZ = 0, firstDist = 0;
-    double lastT = 0.0;  float lastX = 0, lastY = 0, lastZ = 0, lastDist = 0;
-};
-
-static void vio_deposit(VioState& v, double t, float x, float y, float z, float dist)
-{   // particleFilter.c:70-104
-    if (v.firstT == 0.0) {
-        v.firstT = v.lastT = t;
-        v.firstX = v.lastX = x; v.firstY = v.lastY = y; v.firstZ = v.lastZ = z;
-        v.firstDist = v.lastDist = dist;
-        return;
-    }
-    if (dist > v.lastDist) {
-        v.lastDist = dist;
-    } else {
-        const float dx = x - v.lastX, dy = y - v.lastY, dz = z - v.lastZ;
-        v.lastDist += sqrtf(dx * dx + dy * dy + dz * dz);
-    }
-    v.lastT = t; v.lastX = x; v.lastY = y; v.lastZ = z;
-}
-
-static void vio_commit(VioState& v, float d[5])
-{   // particleFilter.c:389-404
-    d[0] = (float)(v.lastT - v.firstT);
-    d[1] = v.lastX - v.firstX; d[2] = v.lastY - v.firstY; d[3] = v.lastZ - v.firstZ;
-    d[4] = v.lastDist - v.firstDist;
-    v.firstT = v.lastT; v.firstX = v.lastX; v.firstY = v.lastY; v.firstZ = v.lastZ; v.firstDist = v.lastDist;
-}
-
 struct ProfRec { hipEvent_t a, b; int kind; };
 
 struct pfx_loc {
@@ -175,12 +147,6 @@ uint32_t next_filter_stream()
 
 namespace {
 
-struct DeviceGuard {
-    int prev = -1;
-    explicit DeviceGuard(int dev) { hipGetDevice(&prev); if (prev != dev) hipSetDevice(dev); else prev = -1; }
-    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
-};
-
 // Kernel timing: the start/stop events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL), so
 // a timed launch costs no extra barrier packet.  (hipEventRecord between two kernels does: measured ~10 us
 // of idle GPU per recorded event on MI355X, 10 % of a deposit.)
@@ -204,13 +170,6 @@ void touch(pfx_loc* pf)
 {   // a state-changing operation
     ++pf->ops;
     if (pf->opsMirror) *pf->opsMirror = pf->ops;
-}
-
-int check_launch(const char* what)
-{
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { set_error("launch of %s failed: %s", what, hipGetErrorString(e)); return -1; }
-    return 0;
 }
 
 int launch_set_ctl(pfx_loc* pf, int cur, int branch, float wscale, int keepCur, int rsValid = 0)
@@ -343,40 +302,6 @@ int launch_pose(pfx_loc* pf)
     hipExtLaunchKernelGGL(k_loc_pose, dim3(1), dim3(kThreads), 0, pf->stream, nullptr, ps.b(), 0, pf->ctl, pf->tileSums, pf->rsPart,
                           pf->numTiles, pf->n);
     return check_launch("k_loc_pose");
-}
-
-Motion motion_of(const float d[5])
-{   // pfMeasurement.c:31-32
-    return Motion{ d[1], d[2], d[3], sqrtf(d[4]) * kVioStdXyz, sqrtf(d[0]) * kVioStdTheta };
-}
-bool is_zero_motion(const float d[5])
-{   // exact zeros only: then x,y,z are unchanged bit for bit and theta only wraps (NaN compares false -> motion)
-    return d[0] == 0.0f && d[1] == 0.0f && d[2] == 0.0f && d[3] == 0.0f && d[4] == 0.0f;
-}
-float float_of_bits(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
-
-Gate gate_of(float bx, float by, float bz, float range, float stdRange)
-{   // pfMeasurement.c:22,114,122
-    const float inf = std::numeric_limits<float>::infinity();
-    Gate g{ bx, by, bz, range, 3 * stdRange, (range < 3.0f) ? 0.1f : 0.5f, 0.0f, inf };    // bounds: everything kept
-    const float r0 = g.range, t0 = g.thresh;
-    if (std::isnan(r0) || std::isnan(t0) || t0 == inf) return g;            // fabsf(..) > thresh is never true
-    if (t0 == -inf || r0 == -inf) { g.d2Lo = inf; g.d2Hi = -1.0f; return g; }   // always true: nothing kept (but NaN)
-    if (r0 == inf) { g.d2Lo = inf; g.d2Hi = inf; return g; }               // only sqrtf(inf) - inf = NaN is kept
-    // e(d2) = sqrtf(d2) - range (float) is non-decreasing in d2 >= 0; the gate keeps |e| <= thresh.  Non-negative floats
-    // are ordered like their bit patterns (0 .. 0x7F800000 = +inf): bisect for the first d2 with e >= -thresh and the
-    // first with e > thresh (both exist: e(+inf) = +inf).
-    const volatile float r = r0, t = t0;
-    auto e_of = [&](uint32_t bits) { const volatile float p = sqrtf(float_of_bits(bits)); const volatile float e = p - r; return (float)e; };
-    uint32_t lo = 0, hi = 0x7F800000u;
-    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (e_of(mid) >= -t) hi = mid; else lo = mid + 1; }
-    const uint32_t first = lo;
-    lo = 0; hi = 0x7F800000u;
-    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (e_of(mid) > t) hi = mid; else lo = mid + 1; }
-    const uint32_t past = lo;
-    if (first >= past) { g.d2Lo = inf; g.d2Hi = -1.0f; }                    // nothing is kept
-    else { g.d2Lo = float_of_bits(first); g.d2Hi = float_of_bits(past - 1); }
-    return g;
 }
 
 int read_ctl(pfx_loc* pf)
@@ -608,11 +533,9 @@ extern "C" void pfx_loc_deposit_vio(pfx_loc* pf, double t, float x, float y, flo
     touch(pf);
 }
 
-extern "C" int pfx_loc_deposit_range(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
-{   // particleFilter.c:178-191
-    clear_error();
-    touch(pf);
-    DeviceGuard g(pf->device);
+namespace {
+int deposit_range_impl(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+{
     float d[5];
     pf->epoch++;
     vio_commit(pf->vio, d);
@@ -643,6 +566,20 @@ extern "C" int pfx_loc_deposit_range(pfx_loc* pf, float bx, float by, float bz, 
     pf->deferKey = key_of(pf);
     pf->deferArg[0] = bx; pf->deferArg[1] = by; pf->deferArg[2] = bz; pf->deferArg[3] = range; pf->deferArg[4] = stdRange;
     return 0;
+}
+}  // namespace
+
+extern "C" int pfx_loc_deposit_range(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange)
+{   // particleFilter.c:178-191
+    clear_error();
+    touch(pf);
+    DeviceGuard g(pf->device);
+    // a launch that fails leaves the VIO accumulator and the deposit count as they were (the call had no effect)
+    const VioState vio0 = pf->vio;
+    const uint32_t epoch0 = pf->epoch;
+    const int rc = deposit_range_impl(pf, bx, by, bz, range, stdRange);
+    if (rc) { pf->vio = vio0; pf->epoch = epoch0; }
+    return rc;
 }
 
 extern "C" int pfx_loc_deposit_rssi(pfx_loc* pf, float bx, float by, float bz, int rssi)
@@ -680,10 +617,25 @@ extern "C" int pfx_loc_upload(pfx_loc* pf, const float* w, const float* x, const
     PF_HIP_OK(hipMemsetAsync(pf->slab, 0, pf->padded * 5 * sizeof(float), pf->stream));
     for (int k = 0; k < 5; ++k)
         PF_HIP_OK(hipMemcpyAsync(pf->bufs.p(0, k), src[k], (size_t)n * sizeof(float), hipMemcpyHostToDevice, pf->stream));
-    if (launch_set_ctl(pf, 0, 0, 1.0f, 0)) return -1;
-    // refresh the per-tile sums so that a pose query right after an upload is served
+    // Weights enter every sum as multiples of 2^-20 (pf_common.h, cdf_units): the path itself keeps the mean weight at 1
+    // (pfResample.c:80-82), where that resolves one part in a million, but a caller's set may be normalised to sum 1 --
+    // at N = 4 M every weight would round to 0 and the filter would have no CDF at all.  A set whose mean lies below
+    // 2^-12 (fewer than eight bits of a typical weight would survive) or whose total reaches 2^33 (where the sums stop
+    // being exact) is therefore brought to mean 1 on its way in, by the factor N / sum w (rounded to float) that the
+    // reference's own normalisation would apply at the next non-resampling deposit; pfx_loc_download then returns the
+    // rescaled weights.  Sets without a positive finite total are taken as they are.
+    float rescale = 1.0f;
+    if (pf->numShards == 1 && !pf->stageSlab) {     // (a shard's weights are a part of a global set: taken as they are)
+        double sum = 0.0;
+        for (int64_t i = 0; i < n; ++i) sum += (double)w[i];
+        const double mean = sum / (double)n;
+        if (std::isfinite(sum) && sum > 0.0 && (mean < 0x1p-12 || sum >= kCdfExactBelow)) rescale = (float)((double)n / sum);
+    }
+    if (launch_set_ctl(pf, 0, 0, rescale, 0)) return -1;
+    // refresh the per-tile sums so that a pose query right after an upload is served (the pass multiplies the factor in)
     float zero[5] = { 0, 0, 0, 0, 0 };
     if (launch_stream(pf, false, false, motion_of(zero), Gate{})) return -1;
+    if (rescale != 1.0f && launch_set_ctl(pf, 0, 0, 1.0f, 1)) return -1;
     PF_HIP_OK(hipStreamSynchronize(pf->stream));
     pf->initialized = initialized != 0;
     pf->poseDirty = true;
@@ -1143,17 +1095,7 @@ extern "C" int pfx_loc_shard_pose_sums(pfx_loc* pf, double out[6])
 extern "C" int pfx_loc_pose_from_sums(pfx_loc* pf, const double p[6], double* t, float* x, float* y, float* z, float* theta)
 {
     if (!pf->initialized) return 0;
-    const float s = (float)p[0], xs = (float)p[1], ys = (float)p[2], zs = (float)p[3], cs = (float)p[4], sn = (float)p[5];
-    *t = pf->vio.lastT;
-    *x = xs / s;
-    *y = ys / s;
-    *z = zs / s;
-    *theta = atan2f(sn, cs);
-    const float dx = pf->vio.lastX - pf->vio.firstX, dy = pf->vio.lastY - pf->vio.firstY, dz = pf->vio.lastZ - pf->vio.firstZ;
-    const float co = cosf(*theta), si = sinf(*theta);
-    *x += dx * co - dy * si;
-    *y += dx * si + dy * co;
-    *z += dz;
+    pose_from_sums_vio(pf->vio, p, t, x, y, z, theta);
     return 1;
 }
 
@@ -1312,11 +1254,15 @@ struct LocStash {
     unsigned long long ops;         // handle->ops when this struct last went through the library
     unsigned long long syncedOps;   // ... when pTag[] was last filled from HBM; kNeverSynced otherwise
     uint32_t seed, streamId, epoch;
+    uint8_t initSeen;               // pf->initialized as the library last wrote it (a caller may set the flag itself)
     int64_t n;
+    uint64_t tagHash;               // of pTag[] as the library last saw or filled it (stage functions, see below)
+    double seenT[2];                // the struct's VIO scalars as the library last wrote them: first/last T,
+    float seenF[8];                 // first X Y Z Dist, last X Y Z Dist (a caller may write the public fields itself)
 };
 constexpr uint64_t kLocMagic = 0x70664C6F63484951ull;   // "pfLocHIQ"
 constexpr unsigned long long kNeverSynced = ~0ull;
-static_assert(sizeof(LocStash) <= sizeof(tagParticle_t) * 8, "binding record must stay a small prefix of pTagBuf");
+static_assert(sizeof(LocStash) <= sizeof(tagParticle_t) * 8 && sizeof(LocStash) == 128, "binding record must stay a small prefix of pTagBuf");
 
 const uint64_t g_process = (uint64_t)time(nullptr) * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)&g_live ^ ((uint64_t)getpid() << 32);
 
@@ -1338,6 +1284,8 @@ pfx_loc* bound(const particleFilterLoc_t* pf)
 
 int64_t legacy_n();
 int legacy_device();
+struct LocStash;
+void note_scalars(LocStash* s, const particleFilterLoc_t* pf);
 
 void note_state(LocStash* s, const pfx_loc* h)
 {
@@ -1349,8 +1297,27 @@ void bind(particleFilterLoc_t* pf, pfx_loc* h)
     LocStash* s = stash_of(pf);
     s->magic = kLocMagic; s->self = (uint64_t)(uintptr_t)pf; s->handle = h; s->process = g_process;
     s->syncedOps = kNeverSynced;
+    note_scalars(s, pf);
     note_state(s, h);
     h->opsMirror = &s->ops;
+}
+
+// pTag[] as 64-bit words through a multiply-xorshift mix (25 us for the reference's 200 kB): tells whether the caller
+// has written to the array since the library last filled or looked at it
+uint64_t tag_hash(const particleFilterLoc_t* pf)
+{
+    const size_t bytes = sizeof(pf->pTag);
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(pf->pTag);
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t v;
+        memcpy(&v, p + i, 8);
+        h = (h ^ v) * 0xD6E8FEB86659FD93ull;
+        h ^= h >> 32;
+    }
+    for (; i < bytes; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+    return h;
 }
 
 VioState vio_of(const particleFilterLoc_t* pf)
@@ -1359,6 +1326,20 @@ VioState vio_of(const particleFilterLoc_t* pf)
     v.firstT = pf->firstT; v.firstX = pf->firstX; v.firstY = pf->firstY; v.firstZ = pf->firstZ; v.firstDist = pf->firstDist;
     v.lastT = pf->lastT; v.lastX = pf->lastX; v.lastY = pf->lastY; v.lastZ = pf->lastZ; v.lastDist = pf->lastDist;
     return v;
+}
+
+void note_scalars(LocStash* s, const particleFilterLoc_t* pf)
+{
+    s->initSeen = pf->initialized ? 1 : 0;
+    s->seenT[0] = pf->firstT; s->seenT[1] = pf->lastT;
+    const float f[8] = { pf->firstX, pf->firstY, pf->firstZ, pf->firstDist, pf->lastX, pf->lastY, pf->lastZ, pf->lastDist };
+    memcpy(s->seenF, f, sizeof f);
+}
+bool scalars_as_noted(const LocStash* s, const particleFilterLoc_t* pf)
+{   // bitwise: a NaN the caller wrote twice is not a change
+    const double t[2] = { pf->firstT, pf->lastT };
+    const float f[8] = { pf->firstX, pf->firstY, pf->firstZ, pf->firstDist, pf->lastX, pf->lastY, pf->lastZ, pf->lastDist };
+    return memcmp(t, s->seenT, sizeof t) == 0 && memcmp(f, s->seenF, sizeof f) == 0;
 }
 
 // the particles of the struct's own pTag[] into `h` (a checkpoint being continued)
@@ -1388,11 +1369,26 @@ pfx_loc* must_be_bound(const particleFilterLoc_t* cpf, const char* fn)
     }
     const bool live = handle_live(s);
     const bool here = s->self == (uint64_t)(uintptr_t)pf;
-    if (live && here && s->ops == s->handle->ops) return s->handle;             // the common case
+    if (live && here && s->ops == s->handle->ops) {                             // the common case
+        pfx_loc* h = s->handle;
+        h->opsMirror = &s->ops;     // (a clone taken from this filter had cleared it)
+        // `initialized` is a public field and the reference's own callers of the stage functions set it themselves
+        // (particleFilter.c:188-189: pfInit_initTagLoc(...); pf->initialized = 1): a value that differs from what the
+        // library last wrote there is the caller's, and counts
+        const uint8_t now = pf->initialized ? 1 : 0;
+        if (now != s->initSeen) { h->initialized = now != 0; s->initSeen = now; h->poseDirty = true; }
+        // likewise the VIO scalars (the reference's golden generators set last* / first* by hand before a pose query)
+        if (!scalars_as_noted(s, pf)) { h->vio = vio_of(pf); note_scalars(s, pf); }
+        return h;
+    }
     const LocStash was = *s;
     if (live && !here && was.ops == was.handle->ops) {
         pfx_loc* c = pfx_loc_clone(was.handle);
         if (!c) { fail(fn); return nullptr; }
+        // The struct the bytes were copied from may be gone by now (a moved or freed original: the copy is all there is),
+        // and the original filter's mirror pointer would then write into freed memory at its next direct pfx_loc_* call:
+        // drop it.  If that struct is still alive and comes through the library again it is re-established above.
+        was.handle->opsMirror = nullptr;
         bind(pf, c);
         return c;
     }
@@ -1429,6 +1425,7 @@ void sync_scalars(particleFilterLoc_t* pf, const pfx_loc* h)
     pf->firstDist = h->vio.firstDist;
     pf->lastT = h->vio.lastT; pf->lastX = h->vio.lastX; pf->lastY = h->vio.lastY; pf->lastZ = h->vio.lastZ;
     pf->lastDist = h->vio.lastDist;
+    note_scalars(stash_of(pf), pf);
     note_state(stash_of(pf), h);
 }
 
@@ -1459,6 +1456,7 @@ extern "C" void particleFilterLoc_init(particleFilterLoc_t* pf)
     }
     bind(pf, h);
     sync_scalars(pf, h);
+    stash_of(pf)->tagHash = tag_hash(pf);       // whatever the caller's array holds now is not the filter's particles
 }
 
 extern "C" void particleFilterLoc_depositVio(particleFilterLoc_t* pf, double t, float x, float y, float z, float dist)
@@ -1495,38 +1493,72 @@ extern "C" uint8_t particleFilterLoc_getTagLoc(const particleFilterLoc_t* pf, do
 }
 
 // ---- the Loc-level stage functions of the reference's internal headers (include/pfStages.h): forwards onto the GPU stages
+// In the reference these work on pf->pTag[] in place, and its golden generators use them that way: fill pTag[], call a
+// stage, read pTag[].  So each forward (1) takes the particles from pf->pTag[] if the caller has written to the array
+// since the library last filled or looked at it (a hash of the array tells), (2) runs the stage on the GPU, and (3)
+// brings pTag[] up to date again.  They are not on the hot path: the deposit / pose entry points above never move
+// particles between host and device.
+extern "C" int pfx_loc_sync_host(particleFilterLoc_t* pf);
+namespace {
+pfx_loc* stage_enter(particleFilterLoc_t* pf, const char* fn)
+{
+    pfx_loc* h = must_be_bound(pf, fn);
+    if (!h) return nullptr;
+    LocStash* s = stash_of(pf);
+    if (h->n <= PF_N_TAG_LOC && tag_hash(pf) != s->tagHash) {
+        const LocStash was = *s;
+        if (restore_from_struct(pf, h, was)) { fail(fn); return nullptr; }
+        note_state(s, h);
+    }
+    return h;
+}
+void stage_exit(particleFilterLoc_t* pf, pfx_loc* h, const char* fn)
+{
+    const uint8_t flag = pf->initialized;               // the stages leave the flag to their caller (particleFilter.c:188-189)
+    const bool init = h->initialized;
+    if (pfx_loc_sync_host(pf)) { fail(fn); return; }
+    h->initialized = init;
+    pf->initialized = flag;
+    stash_of(pf)->initSeen = flag ? 1 : 0;
+}
+}  // namespace
+
 extern "C" void pfRandom_init(void)
 {   // pfRandom.c:56-60
     if (!PF_SEED_SET) PF_SEED = (unsigned int)time(nullptr);
 }
 
 extern "C" void pfInit_initTagLoc(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
-{   // pfInit.c:20-25 (the caller sets pf->initialized, as particleFilter.c:188-189 does)
+{   // pfInit.c:20-25.  The caller sets pf->initialized afterwards, as particleFilter.c:188-189 does: the library picks the
+    // flag up from the struct at the next call (must_be_bound).
     pfx_loc* h = must_be_bound(pf, "pfInit_initTagLoc");
     if (!h) return;
     if (pfx_loc_spawn_all(h, bx, by, bz, range, stdRange)) { fail("pfInit_initTagLoc"); return; }
-    h->initialized = pf->initialized != 0;
+    stage_exit(pf, h, "pfInit_initTagLoc");
 }
 
 extern "C" void pfMeasurement_applyVioLoc(particleFilterLoc_t* pf, float dt, float dx, float dy, float dz, float ddist)
 {   // pfMeasurement.c:24-49
-    pfx_loc* h = must_be_bound(pf, "pfMeasurement_applyVioLoc");
+    pfx_loc* h = stage_enter(pf, "pfMeasurement_applyVioLoc");
     if (!h) return;
-    if (pfx_loc_apply_vio(h, dt, dx, dy, dz, ddist)) fail("pfMeasurement_applyVioLoc");
+    if (pfx_loc_apply_vio(h, dt, dx, dy, dz, ddist)) { fail("pfMeasurement_applyVioLoc"); return; }
+    stage_exit(pf, h, "pfMeasurement_applyVioLoc");
 }
 
 extern "C" void pfMeasurement_applyRangeLoc(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
 {   // pfMeasurement.c:108-125
-    pfx_loc* h = must_be_bound(pf, "pfMeasurement_applyRangeLoc");
+    pfx_loc* h = stage_enter(pf, "pfMeasurement_applyRangeLoc");
     if (!h) return;
-    if (pfx_loc_apply_range(h, bx, by, bz, range, stdRange)) fail("pfMeasurement_applyRangeLoc");
+    if (pfx_loc_apply_range(h, bx, by, bz, range, stdRange)) { fail("pfMeasurement_applyRangeLoc"); return; }
+    stage_exit(pf, h, "pfMeasurement_applyRangeLoc");
 }
 
 extern "C" void pfResample_resampleLoc(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
 {   // pfResample.c:30-84
-    pfx_loc* h = must_be_bound(pf, "pfResample_resampleLoc");
+    pfx_loc* h = stage_enter(pf, "pfResample_resampleLoc");
     if (!h) return;
-    if (pfx_loc_resample(h, bx, by, bz, range, stdRange)) fail("pfResample_resampleLoc");
+    if (pfx_loc_resample(h, bx, by, bz, range, stdRange)) { fail("pfResample_resampleLoc"); return; }
+    stage_exit(pf, h, "pfResample_resampleLoc");
 }
 
 extern "C" pfx_loc* pfx_loc_of(const particleFilterLoc_t* pf) { return bound(pf); }
@@ -1547,6 +1579,7 @@ extern "C" int pfx_loc_sync_host(particleFilterLoc_t* pf)
     sync_scalars(pf, h);
     // from here until the next state-changing call the struct is a complete checkpoint (if it holds all the particles)
     stash_of(pf)->syncedOps = (n <= PF_N_TAG_LOC) ? h->ops : kNeverSynced;
+    stash_of(pf)->tagHash = tag_hash(pf);
     return 0;
 }
 

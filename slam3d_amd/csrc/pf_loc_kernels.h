@@ -54,6 +54,7 @@ struct LocCtl {
     double rStart, rStep;
     double pose[6];     // sum w, w*x, w*y, w*z, w*cos, w*sin of the current particles
     long long nDecisions;   // deposits decided so far (index into the branch log)
+    long long nResampled;   // ... of which resampled
     // Span of this filter inside a (possibly larger, sharded) global filter.  Unsharded: [0,S) x [0,n).
     double shardBase, shardEnd;     // CDF values at the first / past the last local particle
     long long outBegin, outEnd;     // global offspring indices produced from the local particles
@@ -193,13 +194,13 @@ __global__ __launch_bounds__(kThreads) void k_loc_stream(LocBufs bufs, const Loc
 // tileSums already.
 struct TilePieces { const double* sums; const int* headSlot; const int* tailSlot; const double* extra; int lo, hi, n; int direct; };
 
-__global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(double* __restrict__ tileSums, double* __restrict__ tileIncl,
-                                                           double* __restrict__ chunkSums, int numTiles,
-                                                           const LocCtl* __restrict__ ctl, TilePieces pieces)
+__device__ __forceinline__ void chunks_body(double* __restrict__ tileSums, double* __restrict__ tileIncl,
+                                            double* __restrict__ chunkSums, int numTiles,
+                                            const LocCtl* __restrict__ ctl, const TilePieces& pieces, int chunk)
 {
     __shared__ double red[4 * 7];
     __shared__ double sc[4];
-    const int t = blockIdx.x * kChunkTiles + threadIdx.x;
+    const int t = chunk * kChunkTiles + threadIdx.x;
     double v[7] = { 0, 0, 0, 0, 0, 0, 0 };
     if (t < numTiles) {
         double* p = tileSums + (size_t)t * kSumsPerTile;
@@ -241,12 +242,19 @@ __global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(double* __restrict__
     if (t < numTiles) tileIncl[t] = incl;
     __syncthreads();
     block_sum<7>(v, red);
-    if (threadIdx.x == kChunkTiles - 1) chunkSums[(size_t)blockIdx.x * kSumsPerTile] = incl;     // == last prefix, not a re-sum
+    if (threadIdx.x == kChunkTiles - 1) chunkSums[(size_t)chunk * kSumsPerTile] = incl;     // == last prefix, not a re-sum
     if (threadIdx.x == 0) {
-        double* o = chunkSums + (size_t)blockIdx.x * kSumsPerTile;
+        double* o = chunkSums + (size_t)chunk * kSumsPerTile;
 #pragma unroll
         for (int k = 1; k < 7; ++k) o[k] = v[k];
     }
+}
+
+static __global__ __launch_bounds__(kChunkTiles) void k_loc_chunks(double* __restrict__ tileSums, double* __restrict__ tileIncl,
+                                                           double* __restrict__ chunkSums, int numTiles,
+                                                           const LocCtl* __restrict__ ctl, TilePieces pieces)
+{
+    chunks_body(tileSums, tileIncl, chunkSums, numTiles, ctl, pieces, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------ decision (one workgroup)
@@ -302,8 +310,9 @@ __device__ __forceinline__ void decide_commit(LocCtl* __restrict__ ctl, const De
         ctl->wscale = d.m; ctl->m = d.m; ctl->branch = 0; ctl->htheta = 0.0f;
     }
     const long long k = ctl->nDecisions;
-    branchLog[k % kBranchLogSize] = d.resample ? 1 : 0;
+    if (branchLog) branchLog[k % kBranchLogSize] = d.resample ? 1 : 0;     // (the filters of a batch keep the two counts only)
     ctl->nDecisions = k + 1;
+    if (d.resample) ctl->nResampled += 1;
 }
 
 __device__ __forceinline__ bool decide_scalars(LocCtl* __restrict__ ctl, const double (&tot)[7], long long n, float range,
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(64) void k_loc_decide(LocCtl* __restrict__ ctl, con
 // Sharded filter, after the all-gather of every shard's local sums (all[g*8 + k], g in rank order): the same
 // decision on the GLOBAL totals, taken identically by every shard (same inputs, same order of additions), plus
 // this shard's span of the global CDF and the first offspring index of every shard.  One thread.
-__global__ void k_loc_shard_decide(LocCtl* __restrict__ ctl, const double* __restrict__ all, int numShards, int rank,
+static __global__ void k_loc_shard_decide(LocCtl* __restrict__ ctl, const double* __restrict__ all, int numShards, int rank,
                                    long long nGlobal, long long selfBegin, long long selfEnd, float range, RngKey key,
                                    int force, unsigned char* __restrict__ branchLog, ShardPlan* plan,
                                    unsigned long long seq)
@@ -609,11 +618,11 @@ __device__ __forceinline__ void plan_scatter(int chunk, const double* base, cons
 // computes the chunk prefix and the decision (a pure function of the chunk sums: same values everywhere) and keeps the
 // chunk bases in LDS; workgroup 0 alone writes them, and the control block.
 constexpr int kDecideMapThreads = kChunkTiles + 64;
-__global__ __launch_bounds__(kDecideMapThreads) void k_loc_decide_map(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
-                                                            double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
-                                                            DestPlan* __restrict__ plan, int numChunks, int numTiles, long long n,
-                                                            float range, RngKey key, int force,
-                                                            unsigned char* __restrict__ branchLog)
+__device__ __forceinline__ void decide_map_body(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
+                                                double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
+                                                DestPlan* __restrict__ plan, int numChunks, int numTiles, long long n,
+                                                float range, const RngKey& key, int force,
+                                                unsigned char* __restrict__ branchLog, int chunk)
 {
     __shared__ double base[kMaxChunks + 1];
     __shared__ double dec[4];
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(kDecideMapThreads) void k_loc_decide_map(LocCtl* __
     const int tid = threadIdx.x;
     if (tid < 64) {
         double tot[7];
-        const bool first = blockIdx.x == 0;
+        const bool first = chunk == 0;
         float u01 = 0.0f;
         chunk_prefix(chunkSums, numChunks, tot, [&](int c, double v) { base[c] = v; if (first) chunkBase[c] = v; },
                      [&] { u01 = decide_uniform(key); });
@@ -641,7 +650,16 @@ __global__ __launch_bounds__(kDecideMapThreads) void k_loc_decide_map(LocCtl* __
     }
     __syncthreads();
     if (dec[0] == 0.0) return;
-    plan_scatter(blockIdx.x, base, tileIncl, plan, numTiles, n, dec[1], dec[2], dec[3], planLds);
+    plan_scatter(chunk, base, tileIncl, plan, numTiles, n, dec[1], dec[2], dec[3], planLds);
+}
+
+static __global__ __launch_bounds__(kDecideMapThreads) void k_loc_decide_map(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
+                                                            double* __restrict__ chunkBase, const double* __restrict__ tileIncl,
+                                                            DestPlan* __restrict__ plan, int numChunks, int numTiles, long long n,
+                                                            float range, RngKey key, int force,
+                                                            unsigned char* __restrict__ branchLog)
+{
+    decide_map_body(ctl, chunkSums, chunkBase, tileIncl, plan, numChunks, numTiles, n, range, key, force, branchLog, (int)blockIdx.x);
 }
 
 // The global decision of a sharded filter (as k_loc_shard_decide) and the plan records of the shard's destination-owned
@@ -649,7 +667,7 @@ __global__ __launch_bounds__(kDecideMapThreads) void k_loc_decide_map(LocCtl* __
 // pure function of them, so all agree, as in k_loc_decide_map -- and keeps what the plan records need in LDS; workgroup 0
 // alone commits it to the control block and publishes the host's copy.  chunkBase: the shard's LOCAL chunk bases
 // (k_loc_decide<true>).  (As two launches the pair cost 4.5 + 4.9 us of every deposit.)
-__global__ __launch_bounds__(kDecideMapThreads) void k_loc_shard_decide_plan(LocCtl* __restrict__ ctl, const double* __restrict__ all,
+static __global__ __launch_bounds__(kDecideMapThreads) void k_loc_shard_decide_plan(LocCtl* __restrict__ ctl, const double* __restrict__ all,
                                                                              int numShards, int rank, long long nGlobal,
                                                                              long long selfBegin, long long selfEnd, float range,
                                                                              RngKey key, int force, unsigned char* __restrict__ branchLog,
@@ -727,11 +745,11 @@ __global__ __launch_bounds__(kDecideMapThreads) void k_loc_shard_decide_plan(Loc
 // arrays they leave in global memory (tileIncl, chunkSums, chunkBase, plan) are those the big kernels expect; inside the
 // kernel they travel through LDS.
 constexpr int kSmallChunks = PF_SMALL_CHUNKS;
-__global__ __launch_bounds__(kChunkTiles) void k_loc_decide_small(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
-                                                                 double* __restrict__ tileIncl, double* __restrict__ chunkSums,
-                                                                 double* __restrict__ chunkBase, DestPlan* __restrict__ plan,
-                                                                 int numChunks, int numTiles, long long n, float range, RngKey key,
-                                                                 int force, unsigned char* __restrict__ branchLog)
+__device__ __forceinline__ void decide_small_body(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
+                                                  double* __restrict__ tileIncl, double* __restrict__ chunkSums,
+                                                  double* __restrict__ chunkBase, DestPlan* __restrict__ plan,
+                                                  int numChunks, int numTiles, long long n, float range, const RngKey& key,
+                                                  int force, unsigned char* __restrict__ branchLog)
 {
     __shared__ double red[4 * 7];
     __shared__ double sc[4];
@@ -789,6 +807,15 @@ __global__ __launch_bounds__(kChunkTiles) void k_loc_decide_small(LocCtl* __rest
         if (c > 0) __syncthreads();
         plan_scatter(c, base, inclS, plan, numTiles, n, dec[1], dec[2], dec[3], planLds);
     }
+}
+
+static __global__ __launch_bounds__(kChunkTiles) void k_loc_decide_small(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
+                                                                 double* __restrict__ tileIncl, double* __restrict__ chunkSums,
+                                                                 double* __restrict__ chunkBase, DestPlan* __restrict__ plan,
+                                                                 int numChunks, int numTiles, long long n, float range, RngKey key,
+                                                                 int force, unsigned char* __restrict__ branchLog)
+{
+    decide_small_body(ctl, tileSums, tileIncl, chunkSums, chunkBase, plan, numChunks, numTiles, n, range, key, force, branchLog);
 }
 
 // ------------------------------------------------------------------ resample
@@ -1664,7 +1691,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_deposit_sharded(LocBufs bufs, 
 // thread tests one tile with two comparisons, the few tiles that pass are taken one after the other by the whole
 // workgroup, source-owned (resample_deposit_tile<STAGE_ONLY>: tile in LDS, its foreign offspring in a strided loop).
 // Grid: one workgroup per 256 tiles.
-__global__ __launch_bounds__(kThreads) void k_loc_stage_foreign(LocBufs bufs, const LocCtl* __restrict__ ctl,
+static __global__ __launch_bounds__(kThreads) void k_loc_stage_foreign(LocBufs bufs, const LocCtl* __restrict__ ctl,
                                                                const double* __restrict__ chunkBase,
                                                                const double* __restrict__ tileIncl, int numTiles, int n,
                                                                RngKey keyRs, RespawnShell sh, StagePtrs stage)
@@ -1755,9 +1782,9 @@ __global__ __launch_bounds__(kThreads) void k_loc_land(LocBufs bufs, const LocCt
 template <bool PADDED>
 __device__ __forceinline__ void pose_tile_body(const float* __restrict__ pw, const float* __restrict__ px, const float* __restrict__ py,
                                                const float* __restrict__ pz, const float* __restrict__ pt, float wscale, long long n,
-                                               double* __restrict__ part, double* red)
+                                               double* __restrict__ part, double* red, int tile)
 {
-    const long long base = (long long)blockIdx.x * kTile + (long long)threadIdx.x * kPerThread;
+    const long long base = (long long)tile * kTile + (long long)threadIdx.x * kPerThread;
     float w[4], x[4], y[4], z[4], th[4];
     if (PADDED || base + kPerThread <= n) {         // the filter's arrays are padded to whole tiles; a caller's need not be
         const float4 w4 = *reinterpret_cast<const float4*>(pw + base);
@@ -1785,43 +1812,41 @@ __device__ __forceinline__ void pose_tile_body(const float* __restrict__ pw, con
         acc[0] += wi * x[k]; acc[1] += wi * y[k]; acc[2] += wi * z[k];
         acc[3] += wi * cs; acc[4] += wi * sn; acc[5] += cdf_weight(wi);
     }
-    block_sum_store<6>(acc, red, part + (size_t)blockIdx.x * kRsPerTile);
+    block_sum_store<6>(acc, red, part + (size_t)tile * kRsPerTile);
 }
 
-__global__ __launch_bounds__(kThreads) void k_loc_pose_tiles(LocBufs bufs, const LocCtl* __restrict__ ctl,
+static __global__ __launch_bounds__(kThreads) void k_loc_pose_tiles(LocBufs bufs, const LocCtl* __restrict__ ctl,
                                                             double* __restrict__ rsPart, long long n)
 {
     if (ctl->branch != 1 || ctl->rsValid) return;
     __shared__ double red[6 * kThreads];
     const int cur = ctl->cur;
-    pose_tile_body<true>(bufs.p(cur, 0), bufs.p(cur, 1), bufs.p(cur, 2), bufs.p(cur, 3), bufs.p(cur, 4), ctl->wscale, n, rsPart, red);
+    pose_tile_body<true>(bufs.p(cur, 0), bufs.p(cur, 1), bufs.p(cur, 2), bufs.p(cur, 3), bufs.p(cur, 4), ctl->wscale, n, rsPart, red, (int)blockIdx.x);
 }
 
 // The same pass over a CALLER's device arrays, partials into a workspace the caller of the kernel names
 // (pfx_pose_sums_noalloc: the library's static scratch array).
-__global__ __launch_bounds__(kThreads) void k_pose_tiles_raw(const float* __restrict__ pw, const float* __restrict__ px,
+static __global__ __launch_bounds__(kThreads) void k_pose_tiles_raw(const float* __restrict__ pw, const float* __restrict__ px,
                                                             const float* __restrict__ py, const float* __restrict__ pz,
                                                             const float* __restrict__ pt, float wscale, long long n,
                                                             double* __restrict__ part)
 {
     __shared__ double red[6 * kThreads];
-    pose_tile_body<false>(pw, px, py, pz, pt, wscale, n, part, red);
+    pose_tile_body<false>(pw, px, py, pz, pt, wscale, n, part, red, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------ initial spawn (pfInit.c:20-25)
-__global__ __launch_bounds__(kThreads) void k_loc_spawn(LocBufs bufs, LocCtl* __restrict__ ctl, double* __restrict__ rsPart,
-                                                       long long n, long long idx0, RngKey key, float bx, float by, float bz,
-                                                       float range, float stdRange)
+__device__ __forceinline__ void spawn_tile_body(const LocBufs& bufs, int cur, double* __restrict__ rsPart,
+                                                long long n, long long idx0, const RngKey& key, float bx, float by, float bz,
+                                                float range, float stdRange, double* red, int tile)
 {
-    __shared__ double red[6 * kThreads];
-    const int cur = ctl->cur;
     float* __restrict__ pw = bufs.p(cur, 0);
     float* __restrict__ px = bufs.p(cur, 1);
     float* __restrict__ py = bufs.p(cur, 2);
     float* __restrict__ pz = bufs.p(cur, 3);
     float* __restrict__ pt = bufs.p(cur, 4);
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
-    const long long tbase = (long long)blockIdx.x * kTile;
+    const long long tbase = (long long)tile * kTile;
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
         const long long i = tbase + k * kThreads + threadIdx.x;
@@ -1836,11 +1861,19 @@ __global__ __launch_bounds__(kThreads) void k_loc_spawn(LocBufs bufs, LocCtl* __
             pw[i] = 0.0f; px[i] = 0.0f; py[i] = 0.0f; pz[i] = 0.0f; pt[i] = 0.0f;
         }
     }
-    block_sum_store<6>(acc, red, rsPart + (size_t)blockIdx.x * kRsPerTile);
+    block_sum_store<6>(acc, red, rsPart + (size_t)tile * kRsPerTile);
+}
+
+static __global__ __launch_bounds__(kThreads) void k_loc_spawn(LocBufs bufs, LocCtl* __restrict__ ctl, double* __restrict__ rsPart,
+                                                       long long n, long long idx0, RngKey key, float bx, float by, float bz,
+                                                       float range, float stdRange)
+{
+    __shared__ double red[6 * kThreads];
+    spawn_tile_body(bufs, ctl->cur, rsPart, n, idx0, key, bx, by, bz, range, stdRange, red, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------ small control kernels
-__global__ void k_loc_set_ctl(LocCtl* ctl, int cur, int branch, float wscale, int keepCur, int rsValid)
+static __global__ void k_loc_set_ctl(LocCtl* ctl, int cur, int branch, float wscale, int keepCur, int rsValid)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (!keepCur) ctl->cur = cur;
@@ -1870,7 +1903,7 @@ __device__ __forceinline__ void pose_sum_body(const double* __restrict__ tileSum
     block_sum<6>(acc, red);
 }
 
-__global__ __launch_bounds__(kThreads) void k_loc_pose(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
+static __global__ __launch_bounds__(kThreads) void k_loc_pose(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
                                                       const double* __restrict__ rsPart, int numTiles, long long n)
 {
     __shared__ double red[4 * 6];
@@ -1885,7 +1918,7 @@ __global__ __launch_bounds__(kThreads) void k_loc_pose(LocCtl* __restrict__ ctl,
 }
 
 // ... of k_pose_tiles_raw's partials, into the caller's six doubles {sum w, w x, w y, w z, w cos, w sin}
-__global__ __launch_bounds__(kThreads) void k_pose_sum_raw(const double* __restrict__ part, int numTiles, double* __restrict__ out6)
+static __global__ __launch_bounds__(kThreads) void k_pose_sum_raw(const double* __restrict__ part, int numTiles, double* __restrict__ out6)
 {
     __shared__ double red[4 * 6];
     double acc[6];

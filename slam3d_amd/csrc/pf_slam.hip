@@ -877,31 +877,36 @@ void legacy_deposit(particleFilterSlam_t* pf, bcn_t* bcn, float range, float std
     if (target < 0) { fail(fn); return; }
     StepReq r{};
     r.f = 0; r.range = range; r.stdRange = stdRange;
+    // the VIO accumulators are committed into temporaries and stored only once the launches have succeeded: a failing
+    // call (pfx_set_abort_on_error(0)) leaves the structs as it found them
     VioAcc v = vio_load(pf);
     vio_commit(v, r.tagDelta);
-    vio_store(pf, v);
+    VioAcc bvs[kSlamMaxBcns];
     r.activeMask = 0;
     for (int i = 0; i < numBcns; ++i) {
         const int c = slots[i];
-        VioAcc bv = vio_load(allBcns[i]);
-        vio_commit(bv, r.bcnDelta[c]);
-        vio_store(allBcns[i], bv);
+        bvs[i] = vio_load(allBcns[i]);
+        vio_commit(bvs[i], r.bcnDelta[c]);
         r.activeMask |= 1u << c;
         h->fl[0].bcnInit[c] = allBcns[i]->initialized != 0;    // the struct's flag is authoritative
     }
     r.target = target;
-    if (!((r.activeMask >> target) & 1u)) {
+    const bool unlisted = !((r.activeMask >> target) & 1u);
+    VioAcc tv{};
+    if (unlisted) {
         // The measured beacon is not one of allBcns.  Every caller in the reference lists it (csvslam.c:78-85,
         // slam3d-jni.c:52-70); the reference would then skip its VIO commit and, when the tag particles resample, leave
         // its gated weights un-normalised (pfResample.c:122-130).  Here it is treated as listed: one rule for the fused
         // row pass, stated in INTEGRATION.md.
-        VioAcc bv = vio_load(bcn);
-        vio_commit(bv, r.bcnDelta[target]);
-        vio_store(bcn, bv);
+        tv = vio_load(bcn);
+        vio_commit(tv, r.bcnDelta[target]);
         r.activeMask |= 1u << target;
     }
     h->fl[0].bcnInit[r.target] = bcn->initialized != 0;
     if (slam_step(h, &r, 1)) { fail(fn); return; }
+    vio_store(pf, v);
+    for (int i = 0; i < numBcns; ++i) vio_store(allBcns[i], bvs[i]);
+    if (unlisted) vio_store(bcn, tv);
     bcn->initialized = 1;
     note_slam_state(pf, h);
     for (int i = 0; i < numBcns; ++i) stash_of(allBcns[i])->ops = ++h->bcnOps[slots[i]];

@@ -283,6 +283,111 @@ class DeviceParticleFilterLoc:
         return out[:k].copy(), int(total.value)
 
 
+class DeviceLocBatch:
+    """F independent particleFilterLoc filters of n particles each on one GPU, every call one set of launches for the
+    whole batch (pfx_loc_batch_*, include/pfx.h).  The methods are the wrapper's (depositVio / depositRange /
+    depositRssi / getTagLoc) over arrays of F entries; `mask` (F booleans) selects the filters a call applies to."""
+
+    def __init__(self, num_filters: int, n: int = PF_N_TAG_LOC, seed: Optional[int] = None, seeds=None, stream_ids=None,
+                 device: int = 0):
+        self._L = _lib.lib()
+        if seed is None:
+            seed = _seed if _seed is not None else 0
+        self.F, self.n = int(num_filters), int(n)
+        sa = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint32)
+        ia = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.uint32)
+        self._h = self._L.pfx_loc_batch_create(self.F, self.n, None if sa is None else _fptr(sa), int(seed) & 0xFFFFFFFF,
+                                               None if ia is None else _fptr(ia), int(device))
+        if not self._h:
+            raise PfxError(f"pfx_loc_batch_create: {_lib.last_error()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pfx_loc_batch_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _f32(self, a):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float32), (self.F,)))
+        return a
+
+    def _mask(self, mask):
+        if mask is None:
+            return None, None
+        m = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        if m.shape != (self.F,):
+            raise ValueError("mask must have one entry per filter")
+        return m, _fptr(m)
+
+    def seed_of(self, f: int) -> int:
+        return int(self._L.pfx_loc_batch_seed(self._h, int(f)))
+
+    def stream_id_of(self, f: int) -> int:
+        return int(self._L.pfx_loc_batch_stream_id(self._h, int(f)))
+
+    def set_force_branch(self, force: int):
+        check(self._L.pfx_loc_batch_set_force_branch(self._h, int(force)), "pfx_loc_batch_set_force_branch")
+
+    def sync(self):
+        check(self._L.pfx_loc_batch_sync(self._h), "pfx_loc_batch_sync")
+
+    def deposit_vio(self, t, x, y, z, dist=None, mask=None):
+        ta = np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.F,)))
+        xa, ya, za = self._f32(x), self._f32(y), self._f32(z)
+        da = None if dist is None else self._f32(dist)
+        m, mp = self._mask(mask)
+        check(self._L.pfx_loc_batch_deposit_vio(self._h, mp, _fptr(ta), _fptr(xa), _fptr(ya), _fptr(za),
+                                                None if da is None else _fptr(da)), "pfx_loc_batch_deposit_vio")
+
+    def deposit_range(self, bx, by, bz, range, stdRange, mask=None):   # noqa: A002
+        a = [self._f32(v) for v in (bx, by, bz, range, stdRange)]
+        m, mp = self._mask(mask)
+        check(self._L.pfx_loc_batch_deposit_range(self._h, mp, *[_fptr(v) for v in a]), "pfx_loc_batch_deposit_range")
+
+    def deposit_rssi(self, bx, by, bz, rssi=None, mask=None):
+        a = [self._f32(v) for v in (bx, by, bz)]
+        m, mp = self._mask(mask)
+        check(self._L.pfx_loc_batch_deposit_rssi(self._h, mp, *[_fptr(v) for v in a], None), "pfx_loc_batch_deposit_rssi")
+
+    depositVio, depositRange, depositRssi = deposit_vio, deposit_range, deposit_rssi
+
+    def get_tag_loc(self):
+        """(ok uint8[F], t float64[F], x, y, z, theta float32[F]); entries of uninitialised filters are 0"""
+        ok = np.zeros(self.F, dtype=np.uint8)
+        t = np.zeros(self.F, dtype=np.float64)
+        out = [np.zeros(self.F, dtype=np.float32) for _ in range(4)]
+        check(self._L.pfx_loc_batch_get_tag_loc(self._h, _fptr(ok), _fptr(t), *[_fptr(a) for a in out]), "pfx_loc_batch_get_tag_loc")
+        return (ok, t, *out)
+
+    getTagLoc = get_tag_loc
+
+    def download(self, f: int):
+        out = [np.empty(self.n, dtype=np.float32) for _ in range(5)]
+        check(self._L.pfx_loc_batch_download(self._h, int(f), *[_fptr(a) for a in out], self.n), "pfx_loc_batch_download")
+        return tuple(out)
+
+    def last_stats(self, f: int) -> dict:
+        buf = (C.c_double * 12)()
+        check(self._L.pfx_loc_batch_last_stats(self._h, int(f), buf), "pfx_loc_batch_last_stats")
+        keys = ["branch", "numSpawn", "s", "ss", "csum", "ssum", "ess", "htheta", "rStart", "rStep", "m", "S"]
+        return dict(zip(keys, list(buf)))
+
+    def branch_counts(self, per_filter: bool = False):
+        """(deposits decided, of those resampled) since creation, summed over the batch -- or two int64 arrays"""
+        d, r = C.c_int64(), C.c_int64()
+        if per_filter:
+            pd, pr = np.zeros(self.F, dtype=np.int64), np.zeros(self.F, dtype=np.int64)
+            check(self._L.pfx_loc_batch_branch_counts(self._h, C.byref(d), C.byref(r), _fptr(pd), _fptr(pr)), "pfx_loc_batch_branch_counts")
+            return pd, pr
+        check(self._L.pfx_loc_batch_branch_counts(self._h, C.byref(d), C.byref(r), None, None), "pfx_loc_batch_branch_counts")
+        return int(d.value), int(r.value)
+
+
 def resample_indices_f32(cdf, r_start, r_step, device: int = 0) -> np.ndarray:
     """anc[i] = first j with r_start + r_step*i < cdf[j] (float32, pfResample.c:70-72), on the GPU."""
     cdf = np.ascontiguousarray(cdf, dtype=np.float32)

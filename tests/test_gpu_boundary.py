@@ -326,3 +326,36 @@ def test_slam_structs_checkpoint_and_continue():
         assert L.pfx_error_count() == n0 + 1 and b"pfx_slam_sync_host(pf, bcn)" in L.pfx_last_error()
     finally:
         L.pfx_set_abort_on_error(1)
+
+
+def test_upload_of_weights_normalised_to_sum_one():
+    """Weights enter the sums as multiples of 2^-20: a set normalised to SUM 1 at N = 2^22 (every weight
+    2.4e-7) would quantise to nothing.  pfx_loc_upload brings such a set to mean 1 (what the reference's own
+    normalisation does at the next non-resampling deposit, pfResample.c:80-82): the pose and a resampling see the
+    weights' proportions, not zeros."""
+    from slam3d_amd import particlefilter as pfm
+    n = 1 << 22
+    rs = np.random.RandomState(5)
+    x = rs.normal(1.0, 0.5, n).astype(np.float32)
+    y = rs.normal(-2.0, 0.5, n).astype(np.float32)
+    z = rs.normal(0.5, 0.1, n).astype(np.float32)
+    th = rs.uniform(-0.2, 0.2, n).astype(np.float32)
+    w = np.where(np.arange(n) % 4 == 0, 3.0, 1.0)
+    w = (w / w.sum()).astype(np.float32)                      # sum 1: 1.6e-7 .. 4.8e-7 each
+    f = pfm.DeviceParticleFilterLoc(n, seed=3)
+    f.upload(w, x, y, z, th)
+    got = f.download()
+    assert abs(float(got[0].astype(np.float64).mean()) - 1.0) < 1e-6
+    assert np.allclose(got[0] / got[0][1], w / w[1], rtol=1e-6)          # proportions kept
+    ok, _, px, py, pz, pth = f.getTagLoc()
+    wd = w.astype(np.float64)
+    assert ok == 1 and abs(px - float((wd * x).sum() / wd.sum())) < 1e-4 and abs(py - float((wd * y).sum() / wd.sum())) < 1e-4
+    f.set_force_branch(1)
+    f.record_ancestors(True)
+    f.resample(0.0, 0.0, 0.0, 10.0, 0.1)
+    anc = f.last_ancestors()
+    assert np.all(np.diff(anc.astype(np.int64)) >= 0) and anc[0] == 0 and anc[-1] >= n - 4
+    # a heavy particle (3x the weight of its neighbours) has 1.5 x N/sum = 2 offspring on average, a light one 2/3
+    cnt = np.bincount(anc, minlength=n)
+    light = (cnt.sum() - cnt[0::4].sum()) / (0.75 * n)
+    assert abs(cnt[0::4].mean() - 2.0) < 0.01 and abs(light - 2.0 / 3.0) < 0.01

@@ -100,6 +100,13 @@ def main():
     put("resample_static", k, [x for x in ls if x[1] > 12.0 * n], "; resampling side of k_loc_deposit<static>")
     if "stream_static" not in out:
         put("stream_static", k, [x for x in ls if x[1] <= 12.0 * n], "; streaming side of k_loc_deposit<static>")
+    # what the numbers were measured on: bench.py flags `traffic_stale` when the kernel sources have changed since
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pf_common.h", "pf_loc_kernels.h"):
+        with open(os.path.join("slam3d_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    out["_source"] = {"kernel_sources_sha": h.hexdigest()[:16], "command": " ".join(sys.argv)}
     os.makedirs("profiles", exist_ok=True)
     with open("profiles/pmc_traffic.json", "w") as fh:
         json.dump(out, fh, indent=1)
