@@ -487,7 +487,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="timed region without per-kernel HIP events (no roofline)")
     ap.add_argument("--pose-every-step", action="store_true", help="also call getTagLoc after every depositVio (driver pattern)")
     ap.add_argument("--undeferred", action="store_true", help="one resample kernel per deposit (pfx_loc_set_deferred(0))")
-    ap.add_argument("--workload", default="config3", choices=["config3", "config5"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config5", "loc_batch"])
+    ap.add_argument("--batch-filters", type=int, default=1600, help="loc_batch: filters in the batch (each of --particles)")
     ap.add_argument("--slam-filters", type=int, default=512, help="config5: SLAM tags per GPU")
     ap.add_argument("--slam-bcns", type=int, default=4, help="config5: beacons per tag")
     args = ap.parse_args()
@@ -537,6 +538,10 @@ def main():
         return
 
     from slam3d_amd import particlefilter as pfm
+    if args.workload == "loc_batch":        # many Loc filters in one set of launches, by itself (one GPU)
+        nn = args.n if args.n != 16000000 else 10000
+        emit(measure_loc_batch(pfm, torch, local, args.batch_filters, nn, args.steps, args.warmup))
+        return
     if args.total_particles > 0:
         args.n = args.total_particles // world
     K, W, n = args.steps, args.warmup, args.n
@@ -714,7 +719,7 @@ def measure_loc_batch(pfm, torch, local, F, n, K, W=20):
     pre = min(PRE_ROLL, 100)
     for k in range(pre + W):
         one(k)
-    batch.sync()
+    d0, r0 = batch.branch_counts()          # (synchronises)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(pre + W, pre + W + K):
@@ -722,13 +727,15 @@ def measure_loc_batch(pfm, torch, local, F, n, K, W=20):
     batch.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    d1, r1 = batch.branch_counts()
+    frac = (r1 - r0) / max(1, d1 - d0)
     poses = batch.get_tag_loc()
     err = np.linalg.norm(np.stack([poses[2], poses[3], poses[4]], axis=1).astype(np.float64) - truth[pre + W + K - 1 + off], axis=1)
-    step_bytes = 44 + 28 + 40 * 2 * batch.resample_fraction(2 * K)
+    step_bytes = 44 + 28 + 40 * 2 * frac
     gbs = step_bytes * n * F / (dt / K) / 1e9
     return {"filters": F, "particles_per_filter": n, "value": 2.0 * n * F * K / dt, "unit": "particle-updates/s", "steps": K,
             "ms_per_step": dt / K * 1e3, "us_per_filter_step": dt / K / F * 1e6,
-            "resample_fraction": batch.resample_fraction(2 * K), "median_position_error_m": float(np.median(err)),
+            "resample_fraction": frac, "median_position_error_m": float(np.median(err)),
             "step_roofline_frac": gbs / HBM_PEAK_GBS,
             "note": "pfx_loc_batch_*: F independent particleFilterLoc filters of equal N, one set of launches per deposit of the "
                     "whole batch (grid dimension = filter), per-filter Philox stream, per-filter decision on the device"}

@@ -164,6 +164,12 @@ int      pfx_loc_batch_last_stats(pfx_loc_batch* b, int f, double out[12]);
 int      pfx_loc_batch_branch_counts(pfx_loc_batch* b, int64_t* decisions, int64_t* resampled, int64_t* per_filter_decisions,
                                      int64_t* per_filter_resampled);
 
+/* diagnostic: the range gate's squared-distance bounds (pfMeasurement.c:118-123: a particle keeps its weight iff its squared
+ * distance to the beacon lies in [lo, hi]) for `count` (range, stdRange) pairs, derived on the host (single filters) and on
+ * the device (batches); they must agree bit for bit */
+int      pfx_gate_bounds_both(const float* range, const float* stdRange, int count, float* lo_host, float* hi_host,
+                              float* lo_dev, float* hi_dev, int device);
+
 /* ---- one filter sharded by particle range over several GPUs (no counterpart in the reference) ----
  * The caller owns the collectives (slam3d_amd/sharded.py uses torch.distributed = RCCL); these are the local
  * halves of a deposit.  The shard created with pfx_loc_create(n_local, ...) holds the global particles

@@ -131,6 +131,7 @@ def lib() -> C.CDLL:
     sig("pfx_loc_batch_download", i, vp, i, vp, vp, vp, vp, vp, i64)
     sig("pfx_loc_batch_last_stats", i, vp, i, pd_)
     sig("pfx_loc_batch_branch_counts", i, vp, C.POINTER(i64), C.POINTER(i64), vp, vp)
+    sig("pfx_gate_bounds_both", i, vp, vp, i, vp, vp, vp, vp, i)
     # the Loc stage functions of the reference's internal headers (include/pfStages.h)
     sig("pfRandom_init", None)
     sig("pfInit_initTagLoc", None, vp, f, f, f, f, f)

@@ -5,8 +5,9 @@
 // including the deferred resampling: filter f of a batch and a single filter created with its seed and stream id hold
 // the same particles bit for bit after the same calls.
 //
-// Host side of a deposit: O(F) scalar work (VIO commit, Philox keys, flags: ~20 ns per filter), one host-to-device copy
-// of the step records (144 B per filter, from a ring of pinned buffers) and three or four launches.
+// Host side of a deposit: O(F) scalar work (VIO commit, flags: ~10 ns per filter) into a 64-byte record per filter in
+// pinned, device-mapped host memory, and three launches; the first one (k_locb_prepare) reads the records straight from
+// host memory -- no copy engine in the chain.
 #include "pf_loc_batch_kernels.h"
 #include "pf_loc_host.h"
 
@@ -31,9 +32,10 @@ struct pfx_loc_batch {
     int numTiles = 0, numChunks = 0;
     size_t padded = 0;
     LocBatchPtrs B{};
-    BatchStep* dSteps = nullptr;            // [F] on the device (copies are ordered with the kernels on the stream)
-    BatchStep* hSteps[kRing] = {};          // pinned
-    hipEvent_t hFree[kRing] = {};           // recorded behind the copy out of hSteps[i]
+    BatchStep* dSteps = nullptr;            // [F] on the device: the filters' step records (k_locb_prepare keeps them)
+    BatchIn* hSteps[kRing] = {};            // pinned, device-mapped: what the host sends per operation
+    BatchIn* hStepsDev[kRing] = {};         // ... as the device addresses them
+    hipEvent_t hFree[kRing] = {};           // recorded behind the k_locb_prepare that reads hSteps[i]
     bool hUsed[kRing] = {};
     int ring = 0;
     LocCtl* hostCtl = nullptr;              // pinned, [F]
@@ -42,8 +44,6 @@ struct pfx_loc_batch {
     std::vector<VioState> vio;
     std::vector<uint32_t> seed, streamId, epoch;
     std::vector<uint8_t> initialized, poseDirty, deferOpen;
-    std::vector<RngKey> deferKey;
-    std::vector<RespawnShell> deferSh;
 };
 
 namespace {
@@ -96,8 +96,9 @@ int alloc_batch(pfx_loc_batch* b)
     B.padded = b->padded;
     B.numTiles = b->numTiles; B.numChunks = b->numChunks; B.n = (int)b->n; B.numFilters = b->F;
     for (int i = 0; i < kRing; ++i) {
-        PF_HIP_OK(hipHostMalloc((void**)&b->hSteps[i], F * sizeof(BatchStep), hipHostMallocDefault));
-        memset(b->hSteps[i], 0, F * sizeof(BatchStep));
+        PF_HIP_OK(hipHostMalloc((void**)&b->hSteps[i], F * sizeof(BatchIn), hipHostMallocMapped));
+        memset(b->hSteps[i], 0, F * sizeof(BatchIn));
+        PF_HIP_OK(hipHostGetDevicePointer((void**)&b->hStepsDev[i], b->hSteps[i], 0));
         PF_HIP_OK(hipEventCreateWithFlags(&b->hFree[i], hipEventDisableTiming));
     }
     PF_HIP_OK(hipHostMalloc((void**)&b->hostCtl, F * sizeof(LocCtl), hipHostMallocDefault));
@@ -110,17 +111,19 @@ int alloc_batch(pfx_loc_batch* b)
     return 0;
 }
 
-// the next pinned staging buffer (waits for the copy that last read it, normally long finished)
-BatchStep* stage_begin(pfx_loc_batch* b)
+// the next pinned record buffer (waits for the kernel that last read it, normally long finished)
+BatchIn* stage_begin(pfx_loc_batch* b)
 {
     const int i = b->ring;
     if (b->hUsed[i]) hipEventSynchronize(b->hFree[i]);
     return b->hSteps[i];
 }
+// k_locb_prepare on the buffer just filled: the records reach the device, per-deposit scalars and gate bounds are derived
 int stage_send(pfx_loc_batch* b)
 {
     const int i = b->ring;
-    PF_HIP_OK(hipMemcpyAsync(b->dSteps, b->hSteps[i], (size_t)b->F * sizeof(BatchStep), hipMemcpyHostToDevice, b->stream));
+    hipLaunchKernelGGL(k_locb_prepare, dim3((b->F + 63) / 64), dim3(64), 0, b->stream, b->hStepsDev[i], b->dSteps, b->B.ctl, b->F);
+    if (check_launch("k_locb_prepare")) return -1;
     PF_HIP_OK(hipEventRecord(b->hFree[i], b->stream));
     b->hUsed[i] = true;
     b->ring = (i + 1) % kRing;
@@ -153,11 +156,9 @@ int read_ctl_all(pfx_loc_batch* b)
 int materialise_one(pfx_loc_batch* b, int f)
 {
     if (!b->deferOpen[f]) return 0;
-    BatchStep* h = stage_begin(b);
+    BatchIn* h = stage_begin(b);
     for (int g = 0; g < b->F; ++g) { h[g].mode = LB_NONE; h[g].poseWanted = 0; }
     h[f].mode = LB_MATERIALISE;
-    h[f].keyRs = b->deferKey[f];
-    h[f].sh = b->deferSh[f];
     if (stage_send(b)) return -1;
     b->deferOpen[f] = 0;
     return materialise_flagged(b, false);
@@ -196,9 +197,17 @@ extern "C" pfx_loc_batch* pfx_loc_batch_create(int num_filters, int64_t n, const
         b->streamId[f] = stream_ids ? stream_ids[f] : (uint32_t)f;
     }
     b->initialized.assign(F, 0); b->poseDirty.assign(F, 1); b->deferOpen.assign(F, 0);
-    b->deferKey.assign(F, RngKey{}); b->deferSh.assign(F, RespawnShell{});
     DeviceGuard g(device);
     if (alloc_batch(b)) { free_batch(b); delete b; return nullptr; }
+    {   // the filters' Philox key words 0 and 1 live in their device records
+        std::vector<BatchStep> init(F);
+        memset(init.data(), 0, F * sizeof(BatchStep));
+        for (size_t f = 0; f < F; ++f) { init[f].seed = b->seed[f]; init[f].streamId = b->streamId[f]; }
+        if (hipMemcpy(b->dSteps, init.data(), F * sizeof(BatchStep), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("pfx_loc_batch_create: copy of the filter records failed");
+            free_batch(b); delete b; return nullptr;
+        }
+    }
     std::lock_guard<std::mutex> lk(g_bmu);
     g_blive.insert(b);
     return b;
@@ -256,17 +265,16 @@ extern "C" int pfx_loc_batch_deposit_range(pfx_loc_batch* b, const uint8_t* mask
     clear_error();
     if (batch_alive(b, "pfx_loc_batch_deposit_range")) return -2;
     DeviceGuard g(b->device);
-    BatchStep* h = stage_begin(b);
+    BatchIn* h = stage_begin(b);
     int nDeposit = 0, nSpawn = 0, nMoving = 0;
     for (int f = 0; f < b->F; ++f) {
-        BatchStep& r = h[f];
+        BatchIn& r = h[f];
         r.poseWanted = 0;
         if (mask && !mask[f]) { r.mode = LB_NONE; continue; }
         const size_t q = (size_t)f;
-        b->epoch[q]++;
+        r.epoch = ++b->epoch[q];
         vio_commit(b->vio[q], r.d);
         b->poseDirty[q] = 1;
-        r.key = RngKey{ b->seed[q], b->streamId[q], b->epoch[q] };
         r.bx = bx[f]; r.by = by[f]; r.bz = bz[f]; r.range = range[f]; r.stdRange = stdRange[f];
         if (!b->initialized[q]) {               // first range: spawn (particleFilter.c:186-189)
             r.mode = LB_SPAWN;
@@ -279,17 +287,11 @@ extern "C" int pfx_loc_batch_deposit_range(pfx_loc_batch* b, const uint8_t* mask
         r.motion = is_zero_motion(r.d) ? 0 : 1;
         nMoving += r.motion;
         r.fused = b->deferOpen[q];
-        r.keyRs = b->deferKey[q];
-        r.sh = b->deferSh[q];
         b->deferOpen[q] = 1;                    // this deposit's decision stays pending until the next one (or a read)
-        b->deferKey[q] = r.key;
-        b->deferSh[q] = RespawnShell{ r.bx, r.by, r.bz, r.range, r.stdRange };
         ++nDeposit;
     }
     if (nDeposit + nSpawn == 0) return 0;
     if (stage_send(b)) return -1;
-    hipLaunchKernelGGL(k_locb_prepare, dim3((b->F + 63) / 64), dim3(64), 0, b->stream, b->dSteps, b->B.ctl, b->F);
-    if (check_launch("k_locb_prepare")) return -1;
     const dim3 grid(b->numTiles, b->F), block(kThreads);
     if (nSpawn) {
         hipLaunchKernelGGL(k_locb_spawn, grid, block, 0, b->stream, b->B, b->dSteps);
@@ -304,6 +306,10 @@ extern "C" int pfx_loc_batch_deposit_range(pfx_loc_batch* b, const uint8_t* mask
         if (check_launch("k_locb_deposit<static>")) return -1;
     }
     if (nDeposit == 0) return 0;
+    if (b->numTiles <= 64) {
+        hipLaunchKernelGGL(k_locb_decide_tiny, dim3(b->F), dim3(64), 0, b->stream, b->B, b->dSteps, b->force);
+        return check_launch("k_locb_decide_tiny");
+    }
     if (b->numChunks <= kSmallChunks) {
         hipLaunchKernelGGL(k_locb_decide_small, dim3(b->F), dim3(kChunkTiles), 0, b->stream, b->B, b->dSteps, b->force);
         return check_launch("k_locb_decide_small");
@@ -332,7 +338,7 @@ extern "C" int pfx_loc_batch_get_tag_loc(pfx_loc_batch* b, uint8_t* ok, double* 
     int nDirty = 0, nOpen = 0;
     for (int f = 0; f < b->F; ++f) nDirty += (b->initialized[(size_t)f] && b->poseDirty[(size_t)f]) ? 1 : 0;
     if (nDirty) {
-        BatchStep* h = stage_begin(b);
+        BatchIn* h = stage_begin(b);
         for (int f = 0; f < b->F; ++f) {
             const size_t q = (size_t)f;
             const bool want = b->initialized[q] && b->poseDirty[q];
@@ -340,8 +346,6 @@ extern "C" int pfx_loc_batch_get_tag_loc(pfx_loc_batch* b, uint8_t* ok, double* 
             h[f].mode = LB_NONE;
             if (want && b->deferOpen[q]) {
                 h[f].mode = LB_MATERIALISE;
-                h[f].keyRs = b->deferKey[q];
-                h[f].sh = b->deferSh[q];
                 b->deferOpen[q] = 0;
                 ++nOpen;
             }
@@ -412,5 +416,44 @@ extern "C" int pfx_loc_batch_branch_counts(pfx_loc_batch* b, int64_t* decisions,
     }
     if (decisions) *decisions = d;
     if (resampled) *resampled = r;
+    return 0;
+}
+
+// Diagnostic: the squared-distance bounds of the range gate (pfMeasurement.c:118-123) for `count` (range, stdRange)
+// pairs, as the host derives them for a single filter (gate_of) and as k_locb_prepare derives them on the device for the
+// filters of a batch -- the two must agree bit for bit (tests/test_gpu_loc_batch.py).
+extern "C" int pfx_gate_bounds_both(const float* range, const float* stdRange, int count, float* lo_host, float* hi_host,
+                                    float* lo_dev, float* hi_dev, int device)
+{
+    clear_error();
+    if (count < 1) { set_error("pfx_gate_bounds_both: count < 1"); return -2; }
+    DeviceGuard g(device);
+    std::vector<BatchIn> h((size_t)count);
+    memset(h.data(), 0, h.size() * sizeof(BatchIn));
+    for (int i = 0; i < count; ++i) {
+        h[(size_t)i].mode = LB_DEPOSIT;
+        h[(size_t)i].range = range[i];
+        h[(size_t)i].stdRange = stdRange[i];
+        const Gate gh = gate_of(0.f, 0.f, 0.f, range[i], stdRange[i]);
+        lo_host[i] = gh.d2Lo; hi_host[i] = gh.d2Hi;
+    }
+    BatchIn* din = nullptr;
+    BatchStep* d = nullptr;
+    std::vector<BatchStep> out((size_t)count);
+    PF_HIP_OK(hipMalloc((void**)&din, h.size() * sizeof(BatchIn)));
+    if (hipMalloc((void**)&d, out.size() * sizeof(BatchStep)) != hipSuccess) { hipFree(din); set_error("hipMalloc failed"); return -1; }
+    int rc = 0;
+    do {
+        if (hipMemcpy(din, h.data(), h.size() * sizeof(BatchIn), hipMemcpyHostToDevice) != hipSuccess) { rc = -1; break; }
+        if (hipMemset(d, 0, out.size() * sizeof(BatchStep)) != hipSuccess) { rc = -1; break; }
+        hipLaunchKernelGGL(k_locb_prepare, dim3((count + 63) / 64), dim3(64), 0, 0, din, d, (LocCtl*)nullptr, count);
+        if (check_launch("k_locb_prepare")) { rc = -1; break; }
+        if (hipMemcpy(out.data(), d, out.size() * sizeof(BatchStep), hipMemcpyDeviceToHost) != hipSuccess) { rc = -1; break; }
+    } while (0);
+    hipFree(d);
+    hipFree(din);
+    if (rc) { if (!last_error_buf()[0]) set_error("pfx_gate_bounds_both: copy failed"); return rc; }
+    const std::vector<BatchStep>& hh = out;
+    for (int i = 0; i < count; ++i) { lo_dev[i] = hh[(size_t)i].ga.d2Lo; hi_dev[i] = hh[(size_t)i].ga.d2Hi; }
     return 0;
 }

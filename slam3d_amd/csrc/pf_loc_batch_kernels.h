@@ -24,19 +24,41 @@ namespace pf {
 
 enum : int { LB_NONE = 0, LB_DEPOSIT = 1, LB_SPAWN = 2, LB_MATERIALISE = 3 };
 
-// one filter's part of a batched operation (host-filled except mo / ga's bounds)
-struct __attribute__((aligned(16))) BatchStep {
+// What the host sends per filter and operation: 64 bytes in pinned, device-mapped host memory, read by k_locb_prepare
+// itself -- no copy engine between the kernels of two deposits (a hipMemcpyAsync of the full records and its hand-over to
+// the compute queue cost ~15 us per deposit of 1600 filters).
+struct __attribute__((aligned(16))) BatchIn {
     int mode;               // LB_*
     int motion;             // the VIO delta is not all zeros
     int fused;              // a decision is pending whose offspring have not been produced: the pass acts on it
     int poseWanted;         // pose launches: refresh this filter's pose sums
-    RngKey key;             // this deposit's Philox key (seed, stream id, deposit count)
-    RngKey keyRs;           // ... of the deposit whose decision is pending
     float d[5];             // VIO delta: dt dx dy dz ddist (particleFilter.c:389-404)
     float bx, by, bz, range, stdRange;
+    uint32_t epoch;         // the filter's deposit count (Philox counter word 2)
+    int pad;
+};
+static_assert(sizeof(BatchIn) == 64, "one 64-byte record per filter");
+
+// One filter's part of a batched operation as the kernels read it (device memory, one record per filter, persistent):
+// k_locb_prepare fills it from the host's BatchIn, from the control block and from what it remembers of the filter's
+// previous deposit.
+struct __attribute__((aligned(16))) BatchStep {
+    int mode, motion, fused, poseWanted;    // as BatchIn
+    int resample;           // fused and the pending decision was "resample": the pass produces the offspring
+    int cur;                // the control block's current buffer and pending weight factor, for the streaming side
+    float wscale;
+    int pad0;
+    RngKey key;             // this deposit's Philox key (seed, stream id, deposit count)
+    RngKey keyRs;           // ... of the deposit whose decision is pending
+    float d[5];
+    float bx, by, bz, range, stdRange;
     RespawnShell sh;        // measurement of the deposit whose decision is pending (pfResample.c:75-76)
-    Motion mo;              // k_locb_prepare
-    Gate ga;                // k_locb_prepare
+    Motion mo;              // pfMeasurement.c:31-32
+    Gate ga;                // pfMeasurement.c:22,114,118-123
+    // persistent, not read by the O(N) kernels
+    uint32_t seed, streamId;    // Philox key words 0 and 1 of the filter (set at creation)
+    RngKey pendKey;             // key and measurement of the filter's last deposit: what a pending resampling needs
+    RespawnShell pendSh;
 };
 
 struct LocBatchPtrs {
@@ -71,28 +93,67 @@ __device__ __forceinline__ void gate_bounds(Gate& g)
     if (t == -inf || r == -inf) { g.d2Lo = inf; g.d2Hi = -1.0f; return; }
     if (r == inf) { g.d2Lo = inf; g.d2Hi = inf; return; }
     auto e_of = [&](uint32_t bits) { return sqrtf(__uint_as_float(bits)) - r; };
-    uint32_t lo = 0, hi = 0x7F800000u;
-    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (e_of(mid) >= -t) hi = mid; else lo = mid + 1; }
+    // The bisections start from a bracket of +-32 bit patterns around the squared bound, checked with the predicate itself
+    // (monotone in the bit pattern), and fall back to the whole range [0, +inf] if it does not hold: 8 steps instead of 31
+    // for every gate that occurs in practice, the same answer always.
+    auto bracket = [&](float edge, auto pred, uint32_t& lo, uint32_t& hi) {     // first pattern with pred true lies in [lo, hi]
+        lo = 0; hi = 0x7F800000u;
+        if (!(edge > 0.0f)) return;
+        const float sq = edge * edge;
+        if (!(sq < inf)) return;
+        const uint32_t c = __float_as_uint(sq);
+        const uint32_t a = c > 32u ? c - 32u : 0u, b = c + 32u < 0x7F800000u ? c + 32u : 0x7F800000u;
+        if (b == 0x7F800000u || a == 0u) return;
+        if (!pred(a - 1u) && pred(b)) { lo = a; hi = b; }
+    };
+    uint32_t lo, hi;
+    auto ge_lo = [&](uint32_t bits) { return e_of(bits) >= -t; };
+    auto gt_hi = [&](uint32_t bits) { return e_of(bits) > t; };
+    bracket(r - t, ge_lo, lo, hi);
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (ge_lo(mid)) hi = mid; else lo = mid + 1; }
     const uint32_t first = lo;
-    lo = 0; hi = 0x7F800000u;
-    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (e_of(mid) > t) hi = mid; else lo = mid + 1; }
+    bracket(r + t, gt_hi, lo, hi);
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (gt_hi(mid)) hi = mid; else lo = mid + 1; }
     const uint32_t past = lo;
     if (first >= past) { g.d2Lo = inf; g.d2Hi = -1.0f; }
     else { g.d2Lo = __uint_as_float(first); g.d2Hi = __uint_as_float(past - 1); }
 }
 
-__global__ __launch_bounds__(64) void k_locb_prepare(BatchStep* __restrict__ steps, LocCtl* __restrict__ ctl, int numFilters)
+__global__ __launch_bounds__(64) void k_locb_prepare(const BatchIn* __restrict__ in, BatchStep* __restrict__ steps, LocCtl* __restrict__ ctl,
+                                                     int numFilters)
 {
     const int f = blockIdx.x * 64 + threadIdx.x;
     if (f >= numFilters) return;
+    const BatchIn h = in[f];                // (pinned host memory: four 16-byte loads per lane, a wavefront's side by side)
     BatchStep& st = steps[f];
-    if (st.mode == LB_DEPOSIT) {
+    st.mode = h.mode; st.motion = h.motion; st.fused = h.fused; st.poseWanted = h.poseWanted;
+    if (h.mode == LB_DEPOSIT || h.mode == LB_SPAWN) {
+        st.key = RngKey{ st.seed, st.streamId, h.epoch };
+#pragma unroll
+        for (int k = 0; k < 5; ++k) st.d[k] = h.d[k];
+        st.bx = h.bx; st.by = h.by; st.bz = h.bz; st.range = h.range; st.stdRange = h.stdRange;
+    }
+    if (h.mode == LB_DEPOSIT) {
+        // the deposit whose decision may be pending, and this one in its place for the next
+        st.keyRs = st.pendKey; st.sh = st.pendSh;
+        st.pendKey = RngKey{ st.seed, st.streamId, h.epoch };
+        st.pendSh = RespawnShell{ h.bx, h.by, h.bz, h.range, h.stdRange };
         // pfMeasurement.c:31-32, :22, :114, :122
-        st.mo = Motion{ st.d[1], st.d[2], st.d[3], sqrtf(st.d[4]) * kVioStdXyz, sqrtf(st.d[0]) * kVioStdTheta };
-        Gate g{ st.bx, st.by, st.bz, st.range, 3 * st.stdRange, (st.range < 3.0f) ? 0.1f : 0.5f, 0.0f, 0.0f };
+        st.mo = Motion{ h.d[1], h.d[2], h.d[3], sqrtf(h.d[4]) * kVioStdXyz, sqrtf(h.d[0]) * kVioStdTheta };
+        Gate g{ h.bx, h.by, h.bz, h.range, 3 * h.stdRange, (h.range < 3.0f) ? 0.1f : 0.5f, 0.0f, 0.0f };
         gate_bounds(g);
         st.ga = g;
-    } else if (st.mode == LB_SPAWN) {
+        if (ctl) {
+            // what the pass needs of the control block (final by now: the previous deposit's decision precedes this kernel on
+            // the stream), so that a workgroup of the pass has one round trip of scalar loads in front of its particle loads
+            const LocCtl* c = ctl + f;
+            st.resample = (h.fused != 0 && c->branch == 1) ? 1 : 0;
+            st.cur = c->cur;
+            st.wscale = c->wscale;
+        }
+    } else if (h.mode == LB_MATERIALISE) {
+        st.keyRs = st.pendKey; st.sh = st.pendSh;
+    } else if (h.mode == LB_SPAWN) {
         // what k_loc_set_ctl does in front of k_loc_spawn: buffer 0, "resampled", no pending factor, pose partials valid
         LocCtl* c = ctl + f;
         c->cur = 0; c->branch = 1; c->wscale = 1.0f; c->rsValid = 1;
@@ -120,16 +181,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 7))
     union DepositLds { DestLds dest; double red[7 * kThreads]; };
     __shared__ DepositLds L;
     const int f = blockIdx.y, d0 = blockIdx.x;
-    const BatchStep st = steps[f];       // (uniform address: scalar loads, the record sits in scalar registers like kernel arguments)
+    const BatchStep st = steps[f];       // (uniform address: scalar loads; the record sits in scalar registers like kernel arguments)
     if (st.mode != LB_DEPOSIT || (st.motion != 0) != MOTION) return;
     const LocBufs bufs = B.bufs(f);
-    const LocCtl* ctl = B.ctl + f;
-    if (st.fused != 0 && ctl->branch == 1) {
+    // (what the streaming side needs of the control block is in the record: k_locb_prepare)
+    if (st.resample) {
+        const LocCtl* ctl = B.ctl + f;
         const DestPlan P = B.plans(f)[d0];
         resample_dest_tile<1, true, MOTION, false, false>(bufs, ctl, B.cbase(f), B.incl(f), B.numTiles, B.n, st.keyRs, st.sh, st.key,
                                                          st.mo, st.ga, B.sums(f), nullptr, nullptr, P, L.dest, d0);
     } else {
-        stream_tile<MOTION, true>(bufs, ctl, B.sums(f), (long long)B.n, 0, st.key, st.mo, st.ga, L.red, d0);
+        stream_tile_cw<MOTION, true>(bufs, st.cur, st.wscale, B.sums(f), (long long)B.n, 0, st.key, st.mo, st.ga, L.red, d0);
     }
 }
 
@@ -140,6 +202,16 @@ __global__ __launch_bounds__(kChunkTiles) void k_locb_decide_small(LocBatchPtrs 
     if (st.mode != LB_DEPOSIT) return;
     decide_small_body(B.ctl + f, B.sums(f), B.incl(f), B.csums(f), B.cbase(f), B.plans(f), B.numChunks, B.numTiles, (long long)B.n,
                       st.range, st.key, force, nullptr);
+}
+
+// the same for filters of at most 64 tiles: one wavefront per filter (decide_tiny_body)
+__global__ __launch_bounds__(64) void k_locb_decide_tiny(LocBatchPtrs B, const BatchStep* __restrict__ steps, int force)
+{
+    const int f = blockIdx.x;
+    const BatchStep st = steps[f];
+    if (st.mode != LB_DEPOSIT) return;
+    decide_tiny_body(B.ctl + f, B.sums(f), B.incl(f), B.csums(f), B.cbase(f), B.plans(f), B.numTiles, (long long)B.n, st.range, st.key,
+                     force, nullptr);
 }
 
 __global__ __launch_bounds__(kChunkTiles) void k_locb_chunks(LocBatchPtrs B, const BatchStep* __restrict__ steps)

@@ -96,6 +96,10 @@ constexpr int kMaxChunks = 1024;    // one chunk per thread of k_loc_decide: 102
 __device__ __forceinline__ long long first_offspring_at(double b, double rStart, double rStep, long long n);
 
 // ------------------------------------------------------------------ streaming pass
+template <bool MOTION, bool GATE>
+__device__ __forceinline__ void stream_tile_cw(const LocBufs& bufs, int cur, float wscale, double* __restrict__ tileSums, long long n,
+                                               long long idx0, const RngKey& key, const Motion& mo, const Gate& ga, double* red, int tile);
+
 // Body of k_loc_stream (and of the normalise-only side of k_loc_deposit).  `red` holds 7 * kThreads doubles of LDS.
 template <bool MOTION, bool GATE>
 __device__ __forceinline__ void stream_tile(const LocBufs& bufs, const LocCtl* __restrict__ ctl,
@@ -104,8 +108,16 @@ __device__ __forceinline__ void stream_tile(const LocBufs& bufs, const LocCtl* _
 {
     // idx0: global index of local particle 0 (0 unless the filter is one shard of a larger one); the
     // Philox counter uses the global index, so the noise does not depend on how the filter is sharded
-    const int cur = ctl->cur;
-    const float wscale = ctl->wscale;
+    stream_tile_cw<MOTION, GATE>(bufs, ctl->cur, ctl->wscale, tileSums, n, idx0, key, mo, ga, red, tile);
+}
+
+// ... with the two values it needs of the control block handed over (a caller that has loaded them already, together with
+// something else it was waiting for: the batched kernels)
+template <bool MOTION, bool GATE>
+__device__ __forceinline__ void stream_tile_cw(const LocBufs& bufs, int cur, float wscale,
+                                               double* __restrict__ tileSums, long long n, long long idx0,
+                                               const RngKey& key, const Motion& mo, const Gate& ga, double* red, int tile)
+{
     float* __restrict__ pw = bufs.p(cur, 0);
     float* __restrict__ px = bufs.p(cur, 1);
     float* __restrict__ py = bufs.p(cur, 2);
@@ -565,7 +577,7 @@ __device__ __forceinline__ void plan_scatter(int chunk, const double* base, cons
     };
     int t, F;
     fill(tid, t, F);
-    if (blockDim.x == kChunkTiles && tid < 4) {     // a workgroup without the extra wavefront: four threads go twice
+    if (blockDim.x <= kChunkTiles && tid < 4) {     // a workgroup without the extra wavefront: four threads go twice
         int t2, F2;
         fill(kChunkTiles + tid, t2, F2);
     }
@@ -816,6 +828,57 @@ static __global__ __launch_bounds__(kChunkTiles) void k_loc_decide_small(LocCtl*
                                                                  int force, unsigned char* __restrict__ branchLog)
 {
     decide_small_body(ctl, tileSums, tileIncl, chunkSums, chunkBase, plan, numChunks, numTiles, n, range, key, force, branchLog);
+}
+
+// The same for a filter of at most 64 tiles (N <= 65 536: the reference's own 10 000 is ten tiles), by ONE wavefront: no
+// LDS round trips for the sums, no barrier but plan_scatter's.  Batches of such filters take one 64-thread workgroup per
+// filter (k_locb_decide_tiny) instead of a 256-thread one of which three wavefronts add zeros: 14.6 -> ? us per deposit of
+// 1600 filters.  Bit-identical to decide_small_body: the weight totals are exact sums (any order), and the other six sums
+// reduce over the same xor tree of wavefront 0, to which the block version only adds the three zeros of the idle
+// wavefronts.  Called by a workgroup of exactly 64 threads.
+__device__ __forceinline__ void decide_tiny_body(LocCtl* __restrict__ ctl, const double* __restrict__ tileSums,
+                                                 double* __restrict__ tileIncl, double* __restrict__ chunkSums,
+                                                 double* __restrict__ chunkBase, DestPlan* __restrict__ plan,
+                                                 int numTiles, long long n, float range, const RngKey& key,
+                                                 int force, unsigned char* __restrict__ branchLog)
+{
+    __shared__ double cs[kSumsPerTile];
+    __shared__ double inclS[64];
+    __shared__ double base[2];
+    __shared__ double dec[4];
+    __shared__ PlanLds planLds;
+    const int tid = threadIdx.x;
+    double v[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = tid < numTiles ? tileSums[(size_t)tid * kSumsPerTile + k] : 0.0;
+    const float u01 = decide_uniform(key);                  // while the sums are on their way
+    const double incl = wave_inclusive_max_nonneg(wave_inclusive_scan(v[0]));
+    if (tid < numTiles) tileIncl[tid] = incl;
+    inclS[tid] = incl;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) v[k] = wave_sum(v[k]);
+    const double total = __shfl(incl, 63, 64);              // == the last prefix, not a re-sum
+    if (tid == 0) {
+        cs[0] = total; chunkSums[0] = total;
+#pragma unroll
+        for (int k = 1; k < 7; ++k) { cs[k] = v[k]; chunkSums[k] = v[k]; }
+        // the chunk prefix of a single chunk (chunk_prefix with numChunks = 1: base 0, then the total)
+        const double b0 = 0.0 < total ? 0.0 : total;        // (as chunk_prefix caps it: 0 unless the total is 0 or NaN)
+        base[0] = b0; base[1] = total; chunkBase[0] = b0; chunkBase[1] = total;
+        const double tot[7] = { total, v[1], v[2], v[3], v[4], v[5], v[6] };
+        const Decision d = decide_compute(tot, n, range, u01, force);
+        dec[0] = d.resample ? 1.0 : 0.0; dec[1] = d.rStart; dec[2] = d.rStep; dec[3] = d.S;
+        decide_commit(ctl, d, branchLog);
+        if (!d.resample) {
+            ctl->pose[0] = tot[0]; ctl->pose[1] = tot[4]; ctl->pose[2] = tot[5]; ctl->pose[3] = tot[6];
+            ctl->pose[4] = tot[2]; ctl->pose[5] = tot[3];
+        }
+        ctl->shardBase = 0.0; ctl->shardEnd = tot[0];
+        ctl->outBegin = 0; ctl->outEnd = n; ctl->selfBegin = 0; ctl->selfEnd = n; ctl->nGlobal = n;
+    }
+    __syncthreads();
+    if (dec[0] == 0.0) return;
+    plan_scatter(0, base, inclS, plan, numTiles, n, dec[1], dec[2], dec[3], planLds);
 }
 
 // ------------------------------------------------------------------ resample

@@ -126,3 +126,23 @@ def test_batch_rejects_bad_arguments():
         b.download(5)
     with pytest.raises(ValueError):
         b.deposit_range(0.0, 0.0, 0.0, 1.0, 0.1, mask=[1, 0, 1])
+
+
+def test_device_gate_bounds_equal_the_host_bounds():
+    """k_locb_prepare derives the gate's squared-distance bounds on the device (bracketed bisection); single filters get
+    them from the host (gate_of): the same floats for ordinary, tiny, huge, zero, negative, infinite and NaN gates"""
+    import ctypes as C
+    from slam3d_amd import _lib
+    rs = np.random.RandomState(9)
+    r = np.concatenate([rs.uniform(0.0, 30.0, 4000), rs.uniform(0.0, 0.5, 500), 10.0 ** rs.uniform(-30, 30, 500),
+                        [0.0, 1.5, 3.0, 1e-20, 5.0, 5.0, np.inf, 5.0, -np.inf, np.nan, 1e19, 3e38, 1e-45, 2.0]]).astype(np.float32)
+    s = np.concatenate([rs.uniform(0.0, 1.0, 4000), rs.uniform(0.0, 3.0, 500), 10.0 ** rs.uniform(-30, 30, 500),
+                        [0.0, 0.5, 0.0, 1e-21, np.inf, np.nan, 0.1, -0.1, 0.1, 0.1, 1e18, 1e38, 1e-45, 1e30]]).astype(np.float32)
+    n = r.shape[0]
+    out = [np.empty(n, dtype=np.float32) for _ in range(4)]
+    p = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
+    _lib.check(_lib.lib().pfx_gate_bounds_both(p(r), p(s), n, *[p(a) for a in out], 0), "pfx_gate_bounds_both")
+    lo_h, hi_h, lo_d, hi_d = out
+    assert np.array_equal(lo_h.view(np.uint32), lo_d.view(np.uint32))
+    assert np.array_equal(hi_h.view(np.uint32), hi_d.view(np.uint32))
+    assert np.isfinite(lo_h[:4000]).all() and (hi_h[:4000] > lo_h[:4000]).all()
