@@ -192,9 +192,11 @@ int      pfx_gate_bounds_both(const float* range, const float* stdRange, int cou
  *                          (record k of the landing area = local element k for k < lo, else hi + (k - lo), where
  *                          [lo, hi) are the elements the shard produced itself)
  *     pfx_loc_shard_land(1, lo, hi)  the received records are unpacked into the arrays and deposited on
- *     pfx_loc_shard_finish(1, lo, hi)  local tile prefix from the pieces; the 8 local sums land in device memory
+ *     pfx_loc_shard_finish(1, lo, hi)  local tile prefix from the pieces; the shard's chunk sums land in its row
  *   after a "normalise":   pfx_loc_shard_finish(0, 0, 0)
- *   all-gather             of pfx_loc_shard_local_ptr (8 doubles) into pfx_loc_shard_all_ptr (rank-major), by the caller
+ *   all-gather             of the shard's row of chunk sums, pfx_loc_shard_local_ptr (pfx_loc_shard_row_doubles doubles: 8 per
+ *                          262 144 particles of the largest shard; the same on every rank), into pfx_loc_shard_all_ptr
+ *                          (rank-major), by the caller
  *   pfx_loc_shard_decide   the reference's ESS / respawn decision on the GLOBAL totals, identical on every rank;
  *                          returns without waiting.  A "resample" is acted on by the next pfx_loc_shard_deposit.
  * Before anything reads the particles (pose query, download): pfx_loc_shard_plan, and if it says "resample"
@@ -203,8 +205,9 @@ int      pfx_loc_shard_config(pfx_loc* pf, int rank, int num_shards, int64_t n_g
 int      pfx_loc_shard_begin(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);
 int      pfx_loc_shard_deposit(pfx_loc* pf);
 int      pfx_loc_shard_stage(pfx_loc* pf);
-void*    pfx_loc_shard_local_ptr(pfx_loc* pf);      /* device address: s ss csum ssum wx wy wz 0 */
-void*    pfx_loc_shard_all_ptr(pfx_loc* pf);        /* device address: 16 x 8 doubles */
+void*    pfx_loc_shard_local_ptr(pfx_loc* pf);      /* device address: the shard's row, per chunk s ss csum ssum wx wy wz 0 */
+void*    pfx_loc_shard_all_ptr(pfx_loc* pf);        /* device address: 16 rows */
+int64_t  pfx_loc_shard_row_doubles(const pfx_loc* pf);  /* doubles per row (after pfx_loc_shard_config) */
 int      pfx_loc_shard_decide(pfx_loc* pf);
 int      pfx_loc_shard_plan(pfx_loc* pf, int* out_branch, int64_t* out_F);
 /* 0: nothing outstanding; 1: a decision has been launched and neither looked at nor acted on; 2: it was "resample"

@@ -92,6 +92,7 @@ def lib() -> C.CDLL:
     sig("pfx_loc_shard_stage", i, vp)
     sig("pfx_loc_shard_local_ptr", vp, vp)
     sig("pfx_loc_shard_all_ptr", vp, vp)
+    sig("pfx_loc_shard_row_doubles", i64, vp)
     sig("pfx_loc_shard_decide", i, vp)
     sig("pfx_loc_shard_plan", i, vp, C.POINTER(i), C.POINTER(i64))
     sig("pfx_loc_shard_pending", i, vp)

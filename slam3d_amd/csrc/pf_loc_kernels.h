@@ -379,24 +379,16 @@ __device__ __forceinline__ void chunk_prefix(const double* __restrict__ chunkSum
     for (int k = 1; k < 7; ++k) tot[k] = wave_sum(loc[k]);
 }
 
-// The decision of a shard's local pass (LOCAL_ONLY: the sums are published for the all-gather) or of a filter whose
-// resampling stays source-owned: one wavefront.
-template <bool LOCAL_ONLY>
-__global__ __launch_bounds__(64) void k_loc_decide(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
-                                                  double* __restrict__ chunkBase, int numChunks, long long n,
-                                                  float range, RngKey key, int force,
-                                                  unsigned char* __restrict__ branchLog)
+// The decision of a filter whose resampling stays source-owned (a shard driven through the one-filter entry points): one
+// wavefront.
+static __global__ __launch_bounds__(64) void k_loc_decide(LocCtl* __restrict__ ctl, const double* __restrict__ chunkSums,
+                                                         double* __restrict__ chunkBase, int numChunks, long long n,
+                                                         float range, RngKey key, int force,
+                                                         unsigned char* __restrict__ branchLog)
 {
     double tot[7];
     chunk_prefix(chunkSums, numChunks, tot, [&](int c, double v) { chunkBase[c] = v; }, [] {});
     if (threadIdx.x != 0) return;
-    if (LOCAL_ONLY) {
-        // sharded filter: publish the local sums; the decision is taken after the all-gather
-#pragma unroll
-        for (int k = 0; k < 7; ++k) ctl->local[k] = tot[k];
-        ctl->local[7] = 0.0;
-        return;
-    }
     const bool resample = decide_scalars(ctl, tot, n, range, key, force, branchLog);
     if (!resample) {    // the streaming pass's sums are the pose sums of the (unnormalised) current particles
         ctl->pose[0] = tot[0]; ctl->pose[1] = tot[4]; ctl->pose[2] = tot[5]; ctl->pose[3] = tot[6];
@@ -404,44 +396,6 @@ __global__ __launch_bounds__(64) void k_loc_decide(LocCtl* __restrict__ ctl, con
     }
     ctl->shardBase = 0.0; ctl->shardEnd = tot[0];
     ctl->outBegin = 0; ctl->outEnd = n; ctl->selfBegin = 0; ctl->selfEnd = n; ctl->nGlobal = n;
-}
-
-// Sharded filter, after the all-gather of every shard's local sums (all[g*8 + k], g in rank order): the same
-// decision on the GLOBAL totals, taken identically by every shard (same inputs, same order of additions), plus
-// this shard's span of the global CDF and the first offspring index of every shard.  One thread.
-static __global__ void k_loc_shard_decide(LocCtl* __restrict__ ctl, const double* __restrict__ all, int numShards, int rank,
-                                   long long nGlobal, long long selfBegin, long long selfEnd, float range, RngKey key,
-                                   int force, unsigned char* __restrict__ branchLog, ShardPlan* plan,
-                                   unsigned long long seq)
-{   // `plan` lives in pinned host memory: the host polls plan->seq instead of synchronising the stream
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double tot[7] = { 0, 0, 0, 0, 0, 0, 0 };
-    double base[kMaxShards + 1];
-    base[0] = 0.0;
-    for (int g = 0; g < numShards; ++g) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) tot[k] += all[g * 8 + k];
-        base[g + 1] = tot[0];                       // sequential prefix: non-decreasing, base[G] == S exactly
-    }
-    const bool resample = decide_scalars(ctl, tot, nGlobal, range, key, force, branchLog);
-    if (!resample) {    // local part of the pose sums; the host all-reduces them when a pose is asked for
-        const double* l = ctl->local;
-        ctl->pose[0] = l[0]; ctl->pose[1] = l[4]; ctl->pose[2] = l[5]; ctl->pose[3] = l[6]; ctl->pose[4] = l[2]; ctl->pose[5] = l[3];
-    }
-    const double rStart = ctl->rStart, rStep = ctl->rStep;
-    plan->branch = resample ? 1 : 0;
-    plan->numSpawn = ctl->numSpawn; plan->htheta = ctl->htheta; plan->wscale = ctl->wscale;
-    plan->S = tot[0]; plan->rStart = rStart; plan->rStep = rStep;
-    for (int g = 0; g <= numShards; ++g) {
-        long long f = 0;
-        if (resample) f = (g == 0) ? 0 : (g == numShards ? nGlobal : first_offspring_at(base[g], rStart, rStep, nGlobal));
-        plan->F[g] = f;
-    }
-    ctl->shardBase = base[rank]; ctl->shardEnd = base[rank + 1];
-    ctl->outBegin = plan->F[rank]; ctl->outEnd = plan->F[rank + 1];
-    ctl->selfBegin = selfBegin; ctl->selfEnd = selfEnd; ctl->nGlobal = nGlobal;
-    __threadfence_system();
-    __hip_atomic_store(&plan->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // CDF value at the START of tile t (t in [0, numTiles]).  The same expression is evaluated by the
@@ -674,33 +628,65 @@ static __global__ __launch_bounds__(kDecideMapThreads) void k_loc_decide_map(Loc
     decide_map_body(ctl, chunkSums, chunkBase, tileIncl, plan, numChunks, numTiles, n, range, key, force, branchLog, (int)blockIdx.x);
 }
 
-// The global decision of a sharded filter (as k_loc_shard_decide) and the plan records of the shard's destination-owned
-// fused pass, one workgroup per chunk of the shard's tiles: every workgroup takes the decision from the gathered sums -- a
-// pure function of them, so all agree, as in k_loc_decide_map -- and keeps what the plan records need in LDS; workgroup 0
-// alone commits it to the control block and publishes the host's copy.  chunkBase: the shard's LOCAL chunk bases
-// (k_loc_decide<true>).  (As two launches the pair cost 4.5 + 4.9 us of every deposit.)
+// The global decision of a sharded filter and the plan records of the shard's destination-owned fused pass, one workgroup
+// per chunk of the shard's tiles.  Input: the CHUNK SUMS of every shard, `all[g * rowDoubles + c * 8 + k]` (what every
+// shard's k_loc_chunks left, exchanged by one all-gather or written by the shards themselves into each other's tables;
+// rows are zero beyond a shard's last chunk).  Every workgroup of every shard derives from them, with the same additions
+// in the same order: each shard's seven totals (16 threads per shard, 16 partial sums each, added up in a fixed order),
+// the global totals and the decision (a pure function of them, so all agree, as in k_loc_decide_map), where every shard's
+// offspring begin, and -- from the shard's own row -- the local chunk bases the plan records need.  Workgroup 0 alone
+// commits the decision to the control block and publishes the host's copy.
+// (Round 2 had a launch in between that reduced the shard's chunk sums to eight totals for the all-gather,
+// k_loc_decide<LOCAL_ONLY>: 5 us of every deposit, for a message that is latency-bound at 64 bytes and at 2 kB alike.)
+// writePlan = 0: the shard's fused pass is the source-owned one (PFX_SHARD_DIRECT=0), which needs no plan records.
+constexpr int kShardSub = 16;       // partial sums per shard
 static __global__ __launch_bounds__(kDecideMapThreads) void k_loc_shard_decide_plan(LocCtl* __restrict__ ctl, const double* __restrict__ all,
+                                                                             int rowDoubles, int rowChunks,
                                                                              int numShards, int rank, long long nGlobal,
                                                                              long long selfBegin, long long selfEnd, float range,
                                                                              RngKey key, int force, unsigned char* __restrict__ branchLog,
                                                                              ShardPlan* hostPlan, unsigned long long seq,
-                                                                             const double* __restrict__ chunkBase,
+                                                                             double* __restrict__ chunkBase,
                                                                              const double* __restrict__ tileIncl,
-                                                                             DestPlan* __restrict__ plan, int numChunks, int numTiles, int n)
+                                                                             DestPlan* __restrict__ plan, int numChunks, int numTiles, int n,
+                                                                             int writePlan)
 {
     __shared__ double base[kMaxChunks + 1];
     __shared__ PlanLds planLds;
+    __shared__ double part[kMaxShards * kShardSub * 7];
+    __shared__ double totS[kMaxShards * 8];
     __shared__ double decD[6];          // resample, rStart, rStep, S, shardBase, shardEnd
     __shared__ long long decL[2];       // outBegin, outEnd
     const int tid = threadIdx.x;
+    if (tid < kMaxShards * kShardSub) {
+        const int g = tid / kShardSub, sub = tid % kShardSub;
+        double p[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        if (g < numShards) {
+            const double* row = all + (size_t)g * rowDoubles;
+            for (int c = sub; c < rowChunks; c += kShardSub) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) p[k] += row[c * kSumsPerTile + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) part[(g * kShardSub + sub) * 7 + k] = p[k];
+    }
+    __syncthreads();
+    if (tid < kMaxShards * 7) {
+        const int g = tid / 7, k = tid % 7;
+        double t = 0.0;
+        for (int sub = 0; sub < kShardSub; ++sub) t += part[(g * kShardSub + sub) * 7 + k];
+        totS[g * 8 + k] = t;
+    }
+    __syncthreads();
     if (tid < 64) {
-        // every lane of the first wavefront takes the decision (uniform loads, the same arithmetic); lane g then works out
-        // where shard g's offspring begin -- up to seventeen float64 divisions side by side instead of in a row
-        // lane g loads shard g's sums (one round trip for all of them); the totals are then added up shard by shard, in
-        // rank order as k_loc_shard_decide does, every lane the same additions; lane g keeps the prefix in front of shard g
+        // every lane of the first wavefront takes the decision (the same arithmetic on the same values); lane g then works
+        // out where shard g's offspring begin -- up to seventeen float64 divisions side by side instead of in a row.  The
+        // totals are added up shard by shard, in rank order, every lane the same additions; lane g keeps the prefix in
+        // front of shard g
         double mine[7], tot[7] = { 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
-        for (int k = 0; k < 7; ++k) mine[k] = tid < numShards ? all[tid * 8 + k] : 0.0;
+        for (int k = 0; k < 7; ++k) mine[k] = tid < numShards ? totS[tid * 8 + k] : 0.0;
         double myBase = 0.0;                        // start of shard g's span of the global CDF (the total for lane G)
 #pragma unroll 1
         for (int q = 0; q < numShards; ++q) {
@@ -721,8 +707,11 @@ static __global__ __launch_bounds__(kDecideMapThreads) void k_loc_shard_decide_p
             const double sb = __shfl(myBase, rank, 64), se = __shfl(myBase, rank + 1, 64);
             if (tid == 0) {
                 decide_commit(ctl, d, branchLog);
+                const double* l = totS + rank * 8;  // the shard's own totals
+#pragma unroll
+                for (int k = 0; k < 7; ++k) ctl->local[k] = l[k];
+                ctl->local[7] = 0.0;
                 if (!d.resample) {  // local part of the pose sums; the host all-reduces them when a pose is asked for
-                    const double* l = ctl->local;
                     ctl->pose[0] = l[0]; ctl->pose[1] = l[4]; ctl->pose[2] = l[5]; ctl->pose[3] = l[6]; ctl->pose[4] = l[2]; ctl->pose[5] = l[3];
                 }
                 hostPlan->branch = d.resample ? 1 : 0;
@@ -736,10 +725,14 @@ static __global__ __launch_bounds__(kDecideMapThreads) void k_loc_shard_decide_p
             __threadfence_system();
             if (tid == 0) __hip_atomic_store(&hostPlan->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    } else if (tid < 128) {
+        // the second wavefront meanwhile: the shard's LOCAL chunk bases, from its own row of the table
+        double ltot[7];
+        const bool first = blockIdx.x == 0;
+        chunk_prefix(all + (size_t)rank * rowDoubles, numChunks, ltot, [&](int c, double v) { base[c] = v; if (first) chunkBase[c] = v; }, [] {});
     }
-    for (int c = tid; c <= numChunks; c += kDecideMapThreads) base[c] = chunkBase[c];
     __syncthreads();
-    if (decD[0] == 0.0) return;
+    if (decD[0] == 0.0 || !writePlan) return;
     const ShardSpan sp{ decD[4], decD[5], selfBegin, nGlobal, decL[0], decL[1] };
     plan_scatter<true>(blockIdx.x, base, tileIncl, plan, numTiles, n, decD[1], decD[2], decD[3], planLds, sp);
 }

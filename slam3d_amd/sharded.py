@@ -6,7 +6,8 @@ still the wrapper's (depositVio / depositRange / depositRssi / getTagLoc), so th
 Rank g holds the global particles [T_g, T_{g+1}), T_g = floor(g*N/G).  Per deposit:
 
   1. local streaming pass (VIO + gate + sums) and local tile prefix            -- no communication
-  2. all-gather of 8 doubles per rank (sum w, w^2, w cos, w sin, w x, w y, w z) -- RCCL, latency-bound
+  2. all-gather of every rank's chunk sums (sum w, w^2, w cos, w sin, w x, w y, w z per 262 144 particles: 2 kB per
+     rank at 8 M particles per shard)                                          -- RCCL, latency-bound
   3. every rank takes the SAME decision from the gathered sums (same order of additions), and derives
      its span [base_g, base_{g+1}) of the global CDF and the global offspring range [F_g, F_{g+1}) its
      particles produce.  rStart comes from Philox(epoch), identical everywhere: no broadcast.
@@ -96,8 +97,10 @@ class GpuShard:
         # run the library's kernels on torch's current stream so that they are ordered with the collectives
         self._L.pfx_loc_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         dev = f"cuda:{self.device}"
-        self._local = torch.as_tensor(_DevMem(self._L.pfx_loc_shard_local_ptr(self._h), 8, "<f8"), device=dev)
-        self._all = torch.as_tensor(_DevMem(self._L.pfx_loc_shard_all_ptr(self._h), MAX_SHARDS * 8, "<f8"), device=dev)
+        # the exchange table: one row of chunk sums per shard (the shard's own row is what its prefix kernel leaves)
+        self.row = int(self._L.pfx_loc_shard_row_doubles(self._h))
+        self._local = torch.as_tensor(_DevMem(self._L.pfx_loc_shard_local_ptr(self._h), self.row, "<f8"), device=dev)
+        self._all = torch.as_tensor(_DevMem(self._L.pfx_loc_shard_all_ptr(self._h), MAX_SHARDS * self.row, "<f8"), device=dev)
         st, ld, b0, b1 = C.c_void_p(), C.c_void_p(), (C.c_void_p * 5)(), (C.c_void_p * 5)()
         self._lib.check(self._L.pfx_loc_shard_ptrs_both(self._h, C.byref(st), C.byref(ld), b0, b1), "pfx_loc_shard_ptrs_both")
         self._stage = torch.as_tensor(_DevMem(st.value, 4 * self.stage_capacity, "<f4"), device=dev)
@@ -143,7 +146,7 @@ class GpuShard:
         return self._local
 
     def all_sums(self):
-        return self._all[: self.world * 8]
+        return self._all[: self.world * self.row]
 
     def decide(self):
         """the global decision, enqueued; nothing is waited for"""
