@@ -221,6 +221,23 @@ int      pfx_loc_shard_finish(pfx_loc* pf, int pieces, int64_t lo, int64_t hi);
 int      pfx_loc_shard_ptrs_both(pfx_loc* pf, void** d_stage_send, void** d_stage_land, void* d_buf0[5], void* d_buf1[5]);
 int      pfx_loc_shard_cur(const pfx_loc* pf);     /* which of the two buffers is current (after pfx_loc_shard_plan) */
 int      pfx_loc_shard_pose_sums(pfx_loc* pf, double out[6]);   /* local sums of w, wx, wy, wz, w cos, w sin */
+/* -- the same deposit with the collectives inside the library: ONE call per deposit and rank, RCCL called directly on the
+ * shard's stream (ncclAllGather of the rows, ncclSend / ncclRecv of the records), looked up at run time ("librccl.so.1": in
+ * a process that has loaded torch, torch's copy).  The shards must follow the even split T_g = floor(g N / G).  Every rank
+ * makes the same calls in the same order (they are collectives).  No counterpart in the reference. */
+int      pfx_rccl_unique_id(uint8_t out[128]);                          /* ncclGetUniqueId: one rank calls it, all get the bytes */
+int      pfx_loc_shard_comm_init(pfx_loc* pf, const uint8_t id[128]);   /* after pfx_loc_shard_config; collective */
+int      pfx_loc_shard_comm_active(pfx_loc* pf);
+int      pfx_loc_shard_comm_destroy(pfx_loc* pf);
+int      pfx_loc_shard_deposit_range(pfx_loc* pf, float bx, float by, float bz, float range, float stdRange);  /* 1: spawned */
+int      pfx_loc_shard_settle(pfx_loc* pf);                             /* produce an outstanding resampling without a deposit */
+int      pfx_loc_shard_get_tag_loc(pfx_loc* pf, double* t, float* x, float* y, float* z, float* theta);
+int64_t  pfx_loc_shard_exchanged(pfx_loc* pf);                          /* offspring this shard has sent to others so far */
+/* who sends what after a "resample" decision (host arithmetic only, no GPU): F[g]..F[g+1] = global offspring indices shard g
+ * produces; per peer the (offset, count) of the records this shard sends from its staging area and receives into its
+ * landing area; [lo, hi) = the local elements it produced itself */
+int      pfx_shard_exchange_plan(const int64_t* F, int64_t n_global, int world, int rank, int64_t* send_off, int64_t* send_cnt,
+                                 int64_t* recv_off, int64_t* recv_cnt, int64_t* lo, int64_t* hi);
 /* particleFilter.c:274-290 on caller-supplied (e.g. all-reduced) pose sums; 1 ok, 0 not initialised */
 int      pfx_loc_pose_from_sums(pfx_loc* pf, const double sums[6], double* t, float* x, float* y, float* z, float* theta);
 

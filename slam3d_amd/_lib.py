@@ -103,6 +103,15 @@ def lib() -> C.CDLL:
     sig("pfx_loc_shard_cur", i, vp)
     sig("pfx_loc_shard_pose_sums", i, vp, pd_)
     sig("pfx_loc_pose_from_sums", i, vp, pd_, pd_, pf_, pf_, pf_, pf_)
+    sig("pfx_rccl_unique_id", i, vp)
+    sig("pfx_loc_shard_comm_init", i, vp, vp)
+    sig("pfx_loc_shard_comm_active", i, vp)
+    sig("pfx_loc_shard_comm_destroy", i, vp)
+    sig("pfx_loc_shard_deposit_range", i, vp, f, f, f, f, f)
+    sig("pfx_loc_shard_settle", i, vp)
+    sig("pfx_loc_shard_get_tag_loc", i, vp, pd_, pf_, pf_, pf_, pf_)
+    sig("pfx_loc_shard_exchanged", i64, vp)
+    sig("pfx_shard_exchange_plan", i, vp, i64, i, i, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64))
     sig("pfx_pose_sums_noalloc", i, vp, vp, vp, vp, vp, i64, f, vp, vp, i)
     sig("pfx_loc_of", vp, vp)
     sig("pfx_loc_sync_host", i, vp)

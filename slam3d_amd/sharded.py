@@ -26,6 +26,7 @@ oracle-backed CPU stand-in with the same methods to exercise this host logic und
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -175,6 +176,30 @@ class GpuShard:
     def landing_view(self, off, count):
         return self._landing[4 * off: 4 * (off + count)]
 
+    # -- the collectives inside the library (pfx_loc_shard_comm_*): one C call per deposit
+    def comm_init(self, unique_id: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._lib.check(self._L.pfx_loc_shard_comm_init(self._h, buf), "pfx_loc_shard_comm_init")
+
+    def comm_active(self) -> bool:
+        return bool(self._L.pfx_loc_shard_comm_active(self._h))
+
+    def comm_deposit_range(self, bx, by, bz, rng, std) -> int:
+        return self._lib.check(self._L.pfx_loc_shard_deposit_range(self._h, bx, by, bz, rng, std), "pfx_loc_shard_deposit_range")
+
+    def comm_settle(self):
+        self._lib.check(self._L.pfx_loc_shard_settle(self._h), "pfx_loc_shard_settle")
+
+    def comm_get_tag_loc(self):
+        t = C.c_double()
+        x, y, z, th = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        ok = self._lib.check(self._L.pfx_loc_shard_get_tag_loc(self._h, C.byref(t), C.byref(x), C.byref(y), C.byref(z), C.byref(th)),
+                             "pfx_loc_shard_get_tag_loc")
+        return (int(ok), t.value, np.float32(x.value), np.float32(y.value), np.float32(z.value), np.float32(th.value))
+
+    def comm_exchanged(self) -> int:
+        return int(self._L.pfx_loc_shard_exchanged(self._h))
+
     def pose_sums(self):
         out = (C.c_double * 6)()
         self._lib.check(self._L.pfx_loc_shard_pose_sums(self._h, out), "pfx_loc_shard_pose_sums")
@@ -246,11 +271,46 @@ class ShardedLocFilter:
             self.shard = backend_factory(n_local, self.n_total, self.T[self.rank], self.rank, self.world, seed, cap)
         self.stage_capacity = cap
         self._pg_is_nccl = dist.get_backend(group) == "nccl"
+        self._comm = False
+        if backend_factory is None and self._pg_is_nccl and os.environ.get("PFX_SHARD_RCCL", "1") != "0":
+            self._comm = self._init_library_comm()
         self.initialized = False
         self._outstanding = False               # a decision has been launched and not acted on yet
         self._decided = False                   # ... at least one has been launched
         self._plan_cache = None
         self.exchanged_particles = 0
+
+    def _init_library_comm(self) -> bool:
+        """One RCCL communicator inside the library for this filter (pfx_loc_shard_comm_init): a deposit is then one C call per
+        rank.  Collective; every rank ends up with the same answer -- if any rank fails, all stay on the torch path."""
+        torch, dist = self._torch, self._dist
+        from . import _lib
+        ok = 1
+        ident = [None]
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            if _lib.lib().pfx_rccl_unique_id(buf) != 0:
+                ok = 0
+            ident[0] = bytes(buf)
+        dist.broadcast_object_list(ident, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        flag = torch.tensor([ok], device=f"cuda:{self.shard.device}", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            return False
+        try:
+            self.shard.comm_init(ident[0])
+            ok = 1
+        except Exception as e:      # noqa: BLE001 -- whatever went wrong, the torch path still works
+            import sys
+            print(f"slam3d_amd.sharded: in-library RCCL not used on rank {self.rank}: {e}", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], device=f"cuda:{self.shard.device}", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
+
+    @property
+    def uses_library_comm(self) -> bool:
+        return self._comm
 
     # -- collectives (device tensors go straight to RCCL; under gloo they are staged through the host)
     def _all_gather(self, out_t, in_t):
@@ -286,6 +346,8 @@ class ShardedLocFilter:
 
     def _plan(self):
         """(branch, F) of the outstanding decision; read once, when first needed"""
+        if self._comm:
+            return self.shard.plan()            # (the library keeps the state; reading the plan twice is harmless)
         if self._plan_cache is None:
             self._plan_cache = self.shard.plan()
         return self._plan_cache
@@ -316,6 +378,9 @@ class ShardedLocFilter:
 
     def _settle(self):
         """before anything reads the particles: produce a resampling that is still outstanding, without a deposit"""
+        if self._comm:
+            self.shard.comm_settle()
+            return
         if not self._outstanding:
             return
         self._outstanding = False
@@ -330,6 +395,14 @@ class ShardedLocFilter:
 
     def depositRange(self, bx, by, bz, range, stdRange):        # noqa: A002
         sh = self.shard
+        if self._comm:                          # the whole deposit, collectives included, in one library call
+            if sh.comm_deposit_range(bx, by, bz, range, stdRange) == 1:
+                self.initialized = True         # first range: every shard spawned its own particles
+                self._decided = False
+            else:
+                self._decided = True
+            self.exchanged_particles = sh.comm_exchanged()
+            return
         if sh.begin(bx, by, bz, range, stdRange) == 1:
             self.initialized = True             # first range: every shard spawned its own particles
             self._outstanding = self._decided = False
@@ -357,6 +430,8 @@ class ShardedLocFilter:
         torch, dist = self._torch, self._dist
         if not self.initialized:
             return (0, 0.0, np.float32(0), np.float32(0), np.float32(0), np.float32(0))
+        if self._comm:
+            return self.shard.comm_get_tag_loc()
         self._settle()
         sums = torch.from_numpy(self.shard.pose_sums())
         if self._pg_is_nccl:

@@ -187,3 +187,68 @@ def test_exchange_plan_random_boundaries():
                 pos += cnt
             assert pos == lo + (nloc - hi)
         assert (owner >= 0).sum() == sum(max(0, min(F[g + 1], T[g + 1]) - max(F[g], T[g])) for g in range(G))
+
+
+def test_library_exchange_plan_equals_the_python_one():
+    """pfx_shard_exchange_plan (the in-library deposit's shipping plan, host arithmetic only: runs without a GPU) against
+    slam3d_amd.sharded.exchange_plan, which the gloo tests above pin, on random and extreme offspring boundaries"""
+    import ctypes as C
+    from slam3d_amd import _lib
+    from slam3d_amd.sharded import exchange_plan, shard_bounds
+    L = _lib.lib()
+    rs = np.random.RandomState(12)
+    i64 = C.c_int64
+    for it in range(400):
+        G = int(rs.randint(1, 17))
+        n = int(rs.randint(G, 200000)) if it % 7 else int(rs.randint(2 ** 31, 2 ** 32))
+        T = shard_bounds(n, G)
+        cuts = np.sort(rs.randint(0, n + 1, size=G - 1, dtype=np.int64)) if G > 1 else np.array([], dtype=np.int64)
+        if rs.rand() < 0.3 and G > 1:
+            k = int(rs.randint(0, G))
+            cuts = np.array([0] * k + [n] * (G - 1 - k), dtype=np.int64)
+        F = [0] + [int(c) for c in cuts] + [n]
+        Fa = (i64 * (G + 1))(*F)
+        for g in range(G):
+            so, sc, ro, rc = ((i64 * 16)() for _ in range(4))
+            lo, hi = i64(), i64()
+            assert L.pfx_shard_exchange_plan(Fa, n, G, g, so, sc, ro, rc, C.byref(lo), C.byref(hi)) == 0
+            sends, recvs, _ = exchange_plan(F, T, g)
+            elo = min(max(F[g], T[g]), T[g + 1]) - T[g]
+            ehi = max(max(min(F[g + 1], T[g + 1]), T[g]) - T[g], elo)
+            assert (lo.value, hi.value) == (elo, ehi)
+            assert sorted((p, so[p], sc[p]) for p in range(G) if sc[p] > 0) == sorted(sends)
+            exp_recv = sorted((p, off if off < elo else elo + (off - ehi), cnt) for p, off, cnt in recvs)
+            assert sorted((p, ro[p], rc[p]) for p in range(G) if rc[p] > 0) == exp_recv
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("library_comm", ["1", "0"], ids=["in-library-rccl", "torch-collectives"])
+def test_sharded_world1_nccl_matches_single_gpu(library_comm):
+    """One rank, backend nccl (RCCL) on the real GPU: the whole sharded deposit chain, with the collectives called inside
+    the library (pfx_loc_shard_deposit_range: one C call per deposit) or from torch, against the unsharded filter.  With a
+    single shard every sum is the unsharded one in a different order of additions: weights and z EQUAL, the rest to ulps."""
+    from slam3d_amd import particlefilter as pfm
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import sharded_worker as W
+    n, steps = 300007, 14
+    ev = W.events(steps)
+    g = pfm.DeviceParticleFilterLoc(n, seed=123456789)
+    branches = []
+    poses = W.drive(g, ev, lambda f: branches.append(int(f.last_stats()["branch"])), 3)
+    ref = g.download()
+    out = tempfile.mkdtemp(prefix="shard_")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), WORKER, "--backend", "gpu", "--pg", "nccl", "--particles", str(n), "--steps", str(steps),
+           "--pose-every", "3", "--out", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, PFX_SHARD_RCCL=library_comm))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    s = np.load(os.path.join(out, "rank0.npz"))
+    assert int(s["library_comm"]) == int(library_comm)
+    assert np.abs(s["poses"][:, 2:] - poses[:, 2:]).max() <= 1e-4
+    for k, name in enumerate(("w", "x", "y", "z", "th")):
+        if k in (0, 3):
+            assert np.array_equal(s[name], ref[k]), name
+        else:
+            d = np.abs(s[name] - ref[k])
+            assert (np.minimum(d, np.abs(d - 6.2831855)) if k == 4 else d).max() <= 4e-6, name
+    assert 0 < sum(branches) < len(branches)

@@ -98,7 +98,8 @@ def main():
     poses = drive(pf, events(a.steps), tap, a.pose_every)
     w, x, y, z, th = pf.download_local()
     np.savez(os.path.join(a.out, f"rank{rank}.npz"), w=w, x=x, y=y, z=z, th=th, poses=poses,
-             branches=np.array(branches), moved=np.array(moved), T=np.array(pf.T))
+             branches=np.array(branches), moved=np.array(moved), T=np.array(pf.T),
+             library_comm=int(getattr(pf, "uses_library_comm", False)))
     dist.barrier()
     dist.destroy_process_group()
 
