@@ -267,10 +267,10 @@ int slam_step(pfx_slam* pf, const StepReq* req, int nReq)
     }
     if (anyUpdate) {
         if (anyMoving)
-            hipLaunchKernelGGL(k_slam_gate_rows<true>, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo,
+            hipLaunchKernelGGL(k_slam_gate_rows_moving, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo,
                                pf->rowSum, pf->rowScale, pf->rowFlag, pf->forcedList + F);
         else
-            hipLaunchKernelGGL(k_slam_gate_rows<false>, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo,
+            hipLaunchKernelGGL(k_slam_gate_rows_static, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo,
                                pf->rowSum, pf->rowScale, pf->rowFlag, pf->forcedList + F);
         if (check_launch("k_slam_gate_rows")) return -1;
     }

@@ -55,9 +55,15 @@ struct Row4 { float w[4], x[4], y[4], z[4], th[4]; };
 
 __device__ __forceinline__ void row_load(const float* const (&a)[5], size_t base, int j0, int n, Row4& r)
 {
+    // unconditional loads from a clamped index (threads past the row's end read its head and drop it): loads behind a
+    // per-array branch were issued one after the other, each waited for before the next (four round trips instead of one)
+    const int jl = j0 < n ? j0 : 0;
     float4 v[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) v[q] = (j0 < n) ? *reinterpret_cast<const float4*>(a[q] + base + j0) : make_float4(0, 0, 0, 0);
+    for (int q = 0; q < 5; ++q) v[q] = *reinterpret_cast<const float4*>(a[q] + base + jl);
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        if (j0 >= n) v[q] = make_float4(0, 0, 0, 0);
     r.w[0] = v[0].x; r.w[1] = v[0].y; r.w[2] = v[0].z; r.w[3] = v[0].w;
     r.x[0] = v[1].x; r.x[1] = v[1].y; r.x[2] = v[1].z; r.x[3] = v[1].w;
     r.y[0] = v[2].x; r.y[1] = v[2].y; r.y[2] = v[2].z; r.y[3] = v[2].w;
@@ -117,12 +123,62 @@ __device__ __forceinline__ SmallDecision small_decide(double S, double SS, doubl
 
 // Shared-memory working set of one small filter (a tag particle set or one beacon row)
 struct SmallLds {
-    double cdf[kTile];
-    float x[kTile], y[kTile], z[kTile], th[kTile];
+    double cdf[kTile];          // parking space of the block reductions, then the CDF table of a resampling filter (32-bit
+                                // integer offsets in its first half, or float64 values: build_tile_cdf)
+    float4 anc[kTile];          // x y z theta of the filter's particles, staged for the ancestor look-up
     double red[4 * 4];
     double scan[4];
     SmallDecision dec;
 };
+
+// The resampling of one small filter whose decision `d` says so (pfResample.c:115-119 / :178-192), the Loc kernels' way:
+// the CDF goes to LDS as 32-bit integer offsets in units of 2^-20 (exact: the weights enter as multiples of 2^-20 and a
+// filter of <= 1024 particles of mean weight ~1 stays far below the 4095 the form holds; heavier rows take the float64
+// table -- both are the CDF rule of DESIGN.md 4.1, not approximations of it), built with one integer block scan in DPP
+// steps; the ancestors wait in LDS as one float4 each; a thread's four consecutive offspring search from the previous
+// one's ancestor on (three probes, then five levels of three independent probes) instead of ten dependent halving steps
+// over float64; and the unit normals of the thread's first offspring are drawn before the table is looked at.  Same
+// ancestors, same offspring, bit for bit, as the float64 table and halving search of rounds 1-2.
+// r: the filter's particles, four per thread (weights as they enter the CDF); on return the offspring, w = 1.
+__device__ __forceinline__ void small_resample(Row4& r, int j0, int n, SmallLds& L, const SmallDecision& d, double S,
+                                               const RngKey& key, uint64_t index0, float range, float stdRange,
+                                               float cx, float cy, float cz)
+{
+    float nj0[4] = { 0.f, 0.f, 0.f, 0.f };
+    const bool first = j0 < n && j0 >= d.numSpawn;
+    if (first) jitter_normals(key, index0 + (uint64_t)j0, nj0);
+    float wq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        wq[k] = (j0 + k < n) ? r.w[k] : 0.0f;
+        L.anc[j0 + k] = make_float4(r.x[k], r.y[k], r.z[k], r.th[k]);
+    }
+    const bool small = build_tile_cdf(wq, 0.0, S, S, n, L.cdf, L.scan);     // (ends with a barrier: the ancestors are in place too)
+    const uint32_t* const tab32 = reinterpret_cast<const uint32_t*>(L.cdf);
+    int prevJ = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = j0 + k;
+        if (i >= n) continue;
+        if (i < d.numSpawn) {
+            spawn_from_range(key, index0 + (uint64_t)i, cx, cy, cz, range, stdRange, r.x[k], r.y[k], r.z[k], r.th[k]);
+        } else {
+            const double u = d.rStart + d.rStep * (double)i;            // pfResample.c:117 / :180
+            int j;
+            if (small) {
+                const uint32_t q = cvt_u32_sat(u * (double)kCdfScale);
+                j = prevJ >= 0 ? upper_bound_tile_u32_from(tab32, n, q, prevJ) : upper_bound_tile_u32(tab32, n, q);
+            } else {
+                j = upper_bound_tile(L.cdf, n, u);
+            }
+            prevJ = j;
+            const float4 a = L.anc[j];
+            if (k == 0 && first) spawn_from_other_n(nj0, a.x, a.y, a.z, a.w, kHxyz, d.htheta, r.x[k], r.y[k], r.z[k], r.th[k]);
+            else spawn_from_other(key, index0 + (uint64_t)i, a.x, a.y, a.z, a.w, kHxyz, d.htheta, r.x[k], r.y[k], r.z[k], r.th[k]);
+        }
+        r.w[k] = 1.0f;
+    }
+}
 
 // Weight pass + decision + in-register resample/normalise of one small filter of n <= 1024 particles held four
 // per thread in `r` (sn/cs = sin/cos of their headings).  (cx,cy,cz) is the respawn centre; index0 the Philox
@@ -140,13 +196,11 @@ __device__ __forceinline__ SmallDecision small_filter_update(Row4& r, const floa
 {
     const int tid = threadIdx.x;
     double acc[4] = { 0, 0, 0, 0 };     // s, ss, c, sn
-    double a[4];
     double run = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float wi = (j0 + k < n) ? r.w[k] : 0.0f;
         run += cdf_weight(wi);          // exact sums (pf_common.h, CDF rule)
-        a[k] = run;
         acc[1] += wi * wi;
         acc[2] += wi * cs[k];
         acc[3] += wi * sn[k];
@@ -180,31 +234,7 @@ __device__ __forceinline__ SmallDecision small_filter_update(Row4& r, const floa
     __syncthreads();
     const SmallDecision d = L.dec;
     if (d.resample) {                   // uniform over the workgroup
-        double total;
-        const double incl = block_inclusive_scan(run, L.scan, total);
-        const double off = incl - run;
-        const double inf = __builtin_huge_val();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = j0 + k;
-            L.cdf[j] = (j < n) ? off + a[k] : inf;
-            L.x[j] = r.x[k]; L.y[j] = r.y[k]; L.z[j] = r.z[k]; L.th[j] = r.th[k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = j0 + k;
-            if (i >= n) continue;
-            if (i < d.numSpawn) {
-                spawn_from_range(key, index0 + (uint64_t)i, cx, cy, cz, range, stdRange, r.x[k], r.y[k], r.z[k], r.th[k]);
-            } else {
-                const double u = d.rStart + d.rStep * (double)i;        // pfResample.c:117 / :180
-                const int j = upper_bound_tile(L.cdf, n, u);
-                spawn_from_other(key, index0 + (uint64_t)i, L.x[j], L.y[j], L.z[j], L.th[j], kHxyz, d.htheta,
-                                 r.x[k], r.y[k], r.z[k], r.th[k]);
-            }
-            r.w[k] = 1.0f;
-        }
+        small_resample(r, j0, n, L, d, L.red[0], key, index0, range, stdRange, cx, cy, cz);
     } else if (!lazyNorm) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -271,13 +301,9 @@ __device__ __forceinline__ SmallDecision small_filter_update_lazy_theta(Row4& r,
     const float4 t4 = (j0 < n) ? *reinterpret_cast<const float4*>(thSrc + j0) : make_float4(0, 0, 0, 0);
     r.th[0] = t4.x; r.th[1] = t4.y; r.th[2] = t4.z; r.th[3] = t4.w;
     double cs2[2] = { 0, 0 };           // c, sn
-    double a[4];
-    double run = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float wi = (j0 + k < n) ? r.w[k] : 0.0f;
-        run += cdf_weight(wi);
-        a[k] = run;
         r.th[k] = wrap_two_pi(r.th[k]);
         float sn, cs;
         sincos_bounded(r.th[k], sn, cs);
@@ -292,31 +318,7 @@ __device__ __forceinline__ SmallDecision small_filter_update_lazy_theta(Row4& r,
     }
     __syncthreads();
     d = L.dec;
-    double total;
-    const double incl = block_inclusive_scan(run, L.scan, total);
-    const double off = incl - run;
-    const double inf = __builtin_huge_val();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int j = j0 + k;
-        L.cdf[j] = (j < n) ? off + a[k] : inf;
-        L.x[j] = r.x[k]; L.y[j] = r.y[k]; L.z[j] = r.z[k]; L.th[j] = r.th[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = j0 + k;
-        if (i >= n) continue;
-        if (i < d.numSpawn) {
-            spawn_from_range(key, index0 + (uint64_t)i, cx, cy, cz, range, stdRange, r.x[k], r.y[k], r.z[k], r.th[k]);
-        } else {
-            const double u = d.rStart + d.rStep * (double)i;        // pfResample.c:180
-            const int j = upper_bound_tile(L.cdf, n, u);
-            spawn_from_other(key, index0 + (uint64_t)i, L.x[j], L.y[j], L.z[j], L.th[j], kHxyz, d.htheta,
-                             r.x[k], r.y[k], r.z[k], r.th[k]);
-        }
-        r.w[k] = 1.0f;
-    }
+    small_resample(r, j0, n, L, d, L.red[2], key, index0, range, stdRange, cx, cy, cz);
     return d;
 }
 
@@ -325,11 +327,14 @@ __device__ __forceinline__ SmallDecision small_filter_update_lazy_theta(Row4& r,
 // rowFlag[f * nTag + i]: 0 = row i was normalised (lazily), 1 + numSpawn = it was resampled here.
 // ANY_MOVING = false (the host knows that no beacon of the batch moved since its last deposit -- beacons are anchors,
 // csvslam.c never deposits beacon VIO): the headings are not read unless the row resamples (small_filter_update_lazy_theta).
+#ifndef PF_SLAM_STATIC_WAVES
+#define PF_SLAM_STATIC_WAVES 6
+#endif
 template <bool ANY_MOVING>
-__global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
-                                                            const Motion* __restrict__ bcnMo, float* __restrict__ rowSum,
-                                                            float* __restrict__ rowScale, int* __restrict__ rowFlag,
-                                                            int* __restrict__ forcedCount)
+__device__ __forceinline__ void slam_gate_rows_body(const SlamPtrs& P, const SlamDims& D, const SlamStep& one, const SlamStep* __restrict__ many,
+                                                    const Motion* __restrict__ bcnMo, float* __restrict__ rowSum,
+                                                    float* __restrict__ rowScale, int* __restrict__ rowFlag,
+                                                    int* __restrict__ forcedCount)
 {
     const int f = blockIdx.y, i = blockIdx.x;
     if (f == 0 && i == 0 && threadIdx.x == 0) *forcedCount = 0;         // filled by k_slam_tag, read by k_slam_rows_forced
@@ -345,10 +350,17 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDim
     const bool moving = ANY_MOVING && ((st.movingMask >> c) & 1u);
     Row4 r;
     {
+        // (unconditional loads from a clamped index, all in flight together: see row_load)
+        const int jl = j0 < n ? j0 : 0;
+        const bool in = j0 < n;
         float4 v[5];
 #pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(P.bcn[q] + base + jl);
+        v[4] = make_float4(0, 0, 0, 0);
+        if (moving) v[4] = *reinterpret_cast<const float4*>(P.bcn[4] + base + jl);       // uniform over the workgroup
+#pragma unroll
         for (int q = 0; q < 5; ++q)
-            v[q] = (j0 < n && (q < 4 || moving)) ? *reinterpret_cast<const float4*>(P.bcn[q] + base + j0) : make_float4(0, 0, 0, 0);
+            if (!in) v[q] = make_float4(0, 0, 0, 0);
         r.w[0] = v[0].x; r.w[1] = v[0].y; r.w[2] = v[0].z; r.w[3] = v[0].w;
         r.x[0] = v[1].x; r.x[1] = v[1].y; r.x[2] = v[1].z; r.x[3] = v[1].w;
         r.y[0] = v[2].x; r.y[1] = v[2].y; r.y[2] = v[2].z; r.y[3] = v[2].w;
@@ -408,6 +420,23 @@ __global__ __launch_bounds__(kThreads) void k_slam_gate_rows(SlamPtrs P, SlamDim
         rowScale[srow] = d.resample ? 1.0f : d.m;
         rowFlag[(size_t)f * D.nTag + i] = d.resample ? 1 + d.numSpawn : 0;
     }
+}
+
+// some beacon of the batch moved: the rows carry their headings and a motion step (98 registers, 4 waves per SIMD)
+__global__ __launch_bounds__(kThreads) void k_slam_gate_rows_moving(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
+                                                                   const Motion* __restrict__ bcnMo, float* __restrict__ rowSum,
+                                                                   float* __restrict__ rowScale, int* __restrict__ rowFlag,
+                                                                   int* __restrict__ forcedCount)
+{
+    slam_gate_rows_body<true>(P, D, one, many, bcnMo, rowSum, rowScale, rowFlag, forcedCount);
+}
+// no beacon moved (anchors: the usual case)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PF_SLAM_STATIC_WAVES, PF_SLAM_STATIC_WAVES)))
+void k_slam_gate_rows_static(SlamPtrs P, SlamDims D, SlamStep one, const SlamStep* __restrict__ many,
+                             const Motion* __restrict__ bcnMo, float* __restrict__ rowSum, float* __restrict__ rowScale,
+                             int* __restrict__ rowFlag, int* __restrict__ forcedCount)
+{
+    slam_gate_rows_body<false>(P, D, one, many, bcnMo, rowSum, rowScale, rowFlag, forcedCount);
 }
 
 // ------------------------------------------------------------------ the tag particles of every filter
