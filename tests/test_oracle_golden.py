@@ -88,3 +88,61 @@ def test_resample_index_walk_matches_definition(ora):
     # rStart == rStep (uniform() returned exactly 1.0): last offspring falls off the CDF -> clamp
     anc2 = ora.resample_indices_f32(cdf, r_step, r_step)
     assert anc2[-1] == 4999 and np.all(np.diff(anc2) >= 0)
+
+
+def _exact_weights(n=8192):
+    """weights whose running sums are exact in float32 AND in the 2^-20 fixed point of the f64 rule:
+    512 x 4, 1024 x 1, 2048 x 1/2, the rest 0, shuffled.  s = 4096 = n/2 (so rStep = 1/2 exactly, no spawn:
+    s/n >= 0.4 at a long range), ss = 9728, ESS/n = 0.21 (resample)."""
+    w = np.zeros(n, dtype=np.float32)
+    w[:512] = 4.0
+    w[512:1536] = 1.0
+    w[1536:3584] = 0.5
+    np.random.default_rng(11).shuffle(w)
+    return w
+
+
+def test_f32_and_f64_rules_select_the_same_ancestors_on_exact_inputs(ora):
+    """VERDICT r02 item 7a.  ORA_ACC_F32 (the reference's arithmetic, pfResample.c:52-72: serial float32 CDF, float32
+    u_i) and ORA_ACC_F64 (what the HIP path implements: q(w) sums in f64) are the same function wherever neither
+    rounds.  With the weights above both CDFs hold the same multiples of 1/2 exactly and rStep = 1/2 exactly."""
+    n = 8192
+    w = _exact_weights(n)
+    cdf32 = np.cumsum(w, dtype=np.float32)
+    cdf64 = np.cumsum(w.astype(np.float64))
+    assert np.array_equal(cdf32.astype(np.float64), cdf64) and cdf64[-1] == n / 2
+    r_step = 0.5
+    # (1) rStart a power-of-two fraction of rStep: u_i = i/2 + 2^-(k+1) needs <= 24 bits up to k = 10 -> exact in float32
+    for k in range(1, 11):
+        r_start = r_step * 2.0 ** -k
+        a32 = ora.resample_indices_f32(cdf32, r_start, r_step)
+        a64 = ora.resample_indices_f64(cdf64, r_start, r_step)
+        assert np.array_equal(a32, a64), f"k = {k}"
+        u = r_start + r_step * np.arange(n)
+        assert np.array_equal(a64, np.minimum(np.searchsorted(cdf64, u, side="right"), n - 1))
+    # rStart = 0 and rStart = rStep: every u_i EQUAL to a CDF value -- "u < cdf[j]" is false at equality in both
+    for r_start in (0.0, r_step):
+        assert np.array_equal(ora.resample_indices_f32(cdf32, r_start, r_step), ora.resample_indices_f64(cdf64, r_start, r_step))
+    # (2) the whole resample stage, Philox draw shared: uniform() * 1/2 is exact in both modes, so rStart is the same
+    # number; float32 rounds u_i by at most 2^-12 (ulp at 4096 is 2^-11), which cannot carry it across a multiple of
+    # 1/2 while rStart is further than that from 0 and from 1/2.
+    done = 0
+    for epoch in range(1, 9):
+        pfs = []
+        for acc in (ora.ACC_F32, ora.ACC_F64):
+            pf = ora.OracleLoc(n, rng_mode=ora.RNG_PHILOX, seed=2024, acc=acc)
+            z = np.zeros(n, dtype=np.float32)
+            pf.set_particles(w, np.arange(n, dtype=np.float32), z, z, z)
+            pf.set_initialized(1)
+            pf.epoch = epoch
+            pf.resample(0.0, 0.0, 0.0, 10.0, 0.1)
+            pfs.append(pf)
+        s32, s64 = pfs[0].last_stats(), pfs[1].last_stats()
+        assert s32["branch"] == s64["branch"] == 1 and s32["numSpawn"] == s64["numSpawn"] == 0
+        assert s32["rStep"] == s64["rStep"] == 0.5 and s32["rStart"] == s64["rStart"]
+        assert s32["s"] == s64["S"] == n / 2
+        if not (2.0 ** -10 < s64["rStart"] < 0.5 - 2.0 ** -10):
+            continue
+        done += 1
+        assert np.array_equal(pfs[0].last_ancestors(), pfs[1].last_ancestors()), f"epoch {epoch}"
+    assert done >= 6
