@@ -274,36 +274,41 @@ def test_slam_gate_at_its_boundaries(slam, ora, rng_, std, moving):
     """VERDICT r02 item 7b, the SLAM counterpart of test_gpu_loc.py::test_range_gate_at_its_boundaries.  Every row holds
     beacon particles whose distance to the row's tag particle walks float by float across an edge of the 3-sigma shell
     (pfMeasurement.c:118-123 through applyRangeSlam); rows with the tag particle at the origin resolve the edge to one
-    ulp of the distance, the others to one ulp of the position.  Half of the rows have ~50 % of their particles outside
-    (ESS stays high: the row is normalised), half ~90 % (the row resamples).  One particle gated on one side only
-    changes a row sum, the tag weight and, in a resampled row, ancestors: all of it is compared.
-    moving: a tag VIO translation with every heading 0 (cos = 1, sin = 0: x + dx rounds the same on both sides), which
-    runs k_slam_gate_rows_moving; otherwise zero motion, k_slam_gate_rows_static."""
+    ulp of the distance, the others to one ulp of the position.  Even row pairs carry uniform weights (a gated weight is
+    halved, so the ESS stays high and the row is normalised), odd pairs carry their weight on 100 particles (the row
+    resamples).  One particle gated on one side only changes a row sum, the tag weight and, in a resampled row,
+    ancestors: all of it is compared.
+    moving: the beacon has a VIO delta of 1e-30 m at dt = 0 -- a motion as far as the library is concerned, so
+    k_slam_gate_rows_moving and k_slam_rows run, but one whose noise scales sqrtf(ddist) and sqrtf(dt) are 0 and whose
+    translation is absorbed by rounding, so every distance is still the one laid out here.  Otherwise no beacon VIO:
+    k_slam_gate_rows_static.  The tag particles take a zero translation over dt = 1 (heading noise only)."""
     n_tag, n_bcn = 100, 1000
     g = slam.DeviceParticleFilterSlam(n_tag, n_bcn, seed=99, max_bcns=2)
     o = ora.OracleSlam(n_tag, n_bcn, rng_mode=ora.RNG_PHILOX, seed=99, acc=ora.ACC_F64)
     gb, ob = g.addBcn(), o.addBcn()
-    for pf in (g, o):
+    for pf, b in ((g, gb), (o, ob)):
         pf.depositTagVio(1.0, 0.0, 0.0, 0.0, 0.0)
+        b.depositVio(1.0, 0.0, 0.0, 0.0, 0.0)
     g.depositRange(gb, 3.0, 0.1)                           # first range: spawns the rows (epoch 1 on both sides)
     o.depositRange(ob, 3.0, 0.1)
     rs = np.random.default_rng(5)
     tag = np.zeros((5, n_tag), dtype=np.float32)
     tag[0] = 1.0
     tag[1:4, n_tag // 4:] = rs.uniform(-20, 20, size=(3, n_tag - n_tag // 4)).astype(np.float32)   # first quarter at the origin
-    shift = np.float32(0.375) if moving else np.float32(0.0)
+    tag[4] = rs.uniform(0, 6.28, size=n_tag).astype(np.float32)
     r, t = np.float32(rng_), np.float32(3.0) * np.float32(std)
     edges = [e for e in (r - t, r + t) if e > 0]
     bcn = np.zeros((5, n_tag, n_bcn), dtype=np.float32)
     bcn[0] = 1.0
     bcn[4] = rs.uniform(0, 6.28, size=(n_tag, n_bcn)).astype(np.float32)
     dirs = np.eye(3, dtype=np.float32)
+    concentrated = np.zeros(n_tag, dtype=bool)
     for i in range(n_tag):
         e = edges[i % len(edges)]
         d = _walk(e, 250)                                  # 501 floats around the edge
         inside = np.float32(rng_)                          # on the shell
         outside = np.float32(rng_ + 10.0 * max(std, 0.01) + 1.0)
-        filler = outside if (i // 2) % 2 else inside       # the other 499: all outside (row resamples) or all inside
+        filler = outside if (i // 4) % 2 else inside
         dist = np.concatenate([d, np.full(n_bcn - d.size, filler, dtype=np.float32)])
         rs.shuffle(dist)
         if i % 3 == 2:                                     # on a diagonal: d2 = h*h + h*h
@@ -311,17 +316,22 @@ def test_slam_gate_at_its_boundaries(slam, ora, rng_, std, moving):
             off = np.stack([h, np.zeros_like(h), h])
         else:
             off = dirs[i % 3][:, None] * dist[None, :] * np.float32(1.0 if i % 2 else -1.0)
-        # the beacon particle sits where the tag particle WILL be (after the shift along x) plus the offset
         for k in range(3):
-            bcn[1 + k, i] = (tag[1 + k, i] + (shift if k == 0 else np.float32(0.0))) + off[k].astype(np.float32)
+            bcn[1 + k, i] = tag[1 + k, i] + off[k].astype(np.float32)
+        if (i // 2) % 2:
+            concentrated[i] = True
+            bcn[0, i] = np.float32(2.0 ** -7)
+            bcn[0, i, rs.choice(n_bcn, size=100, replace=False)] = 1.0
     g.batch.upload_tag(0, *tag)
     g.batch.upload_bcn(0, gb.slot, *bcn, initialized=True)
     for dst, src in zip(o.arrays(), tag):
         dst[:] = src
     for dst, src in zip(ob.arrays(), bcn):
         dst[:] = src
-    for pf in (g, o):
-        pf.depositTagVio(2.0, float(shift), 0.0, 0.0, 0.0)
+    for pf, b in ((g, gb), (o, ob)):
+        pf.depositTagVio(2.0, 0.0, 0.0, 0.0, 0.0)
+        if moving:
+            b.depositVio(1.0, 1e-30, 0.0, 0.0, 0.0)
     g.depositRange(gb, float(rng_), float(std))
     o.depositRange(ob, float(rng_), float(std))
     assert g.last_tag_resampled == o.last_tag_resampled
@@ -329,18 +339,24 @@ def test_slam_gate_at_its_boundaries(slam, ora, rng_, std, moving):
     gw, ow = gb.arrays(), ob.arrays()
     _close_particles(ga, oa, "tag particles")
     _close_particles(gw, ow, "beacon particles")
-    if not o.last_tag_resampled:
-        # row by row: a resampled row has all weights 1, a normalised one keeps its pattern -- identical either way
-        res_o = np.all(ow[0] == 1.0, axis=1)
-        res_g = np.all(gw[0] == 1.0, axis=1)
-        assert np.array_equal(res_o, res_g)
-        assert 0 < int(res_o.sum()) < n_tag, "both row branches should occur"
-        keep = ~res_o
-        # which particles were gated (weight below the row's maximum) must agree exactly
-        assert np.array_equal(gw[0][keep] < gw[0][keep].max(axis=1, keepdims=True),
-                              ow[0][keep] < ow[0][keep].max(axis=1, keepdims=True))
-        # positions of a row that was not resampled are untouched by the deposit (beacon VIO is zero)
-        assert np.array_equal(gw[1][keep], ow[1][keep]) and np.array_equal(gw[1][keep], bcn[1][keep])
+    assert not o.last_tag_resampled
+    # row by row: a resampled row has all weights 1, a normalised one keeps its pattern -- identical either way
+    res_o = np.all(ow[0] == 1.0, axis=1)
+    res_g = np.all(gw[0] == 1.0, axis=1)
+    assert np.array_equal(res_o, res_g)
+    assert np.all(res_o[concentrated]) and 0 < int(res_o.sum()) < n_tag, "both row branches should occur"
+    keep = ~res_o
+    # which particles were gated (weight below the row's maximum) must agree exactly
+    gated_g = gw[0][keep] < gw[0][keep].max(axis=1, keepdims=True)
+    gated_o = ow[0][keep] < ow[0][keep].max(axis=1, keepdims=True)
+    assert np.array_equal(gated_g, gated_o)
+    assert 0 < int(gated_o.sum()) < gated_o.size
+    # positions of a row that was not resampled are what was uploaded (zero or absorbed beacon motion)
+    # (a coordinate that was exactly 0 becomes 1e-30 * cos or sin of the heading: equal to the oracle's to ~1e-36 only)
+    for k in (1, 2, 3):
+        far = np.abs(bcn[k][keep]) > 1e-20
+        assert np.array_equal(gw[k][keep][far], bcn[k][keep][far]) and np.array_equal(ow[k][keep][far], bcn[k][keep][far])
+        assert np.abs(gw[k][keep][~far] - ow[k][keep][~far]).max(initial=0.0) <= 1e-29
     pa, pb = g.getBcnLoc(gb), o.getBcnLoc(ob)
     assert pa[0] == pb[0] == 1
     assert np.abs(np.array(pa[2:5], dtype=np.float64) - np.array(pb[2:5], dtype=np.float64)).max() <= 2e-5
