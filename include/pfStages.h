@@ -3,10 +3,14 @@
  *
  * The reference installs pfInit.h / pfMeasurement.h / pfResample.h / pfRandom.h beside particleFilter.h and leaves
  * their functions visible in its shared object (nothing there is static).  No caller in the reference uses them, but
- * a program that does keeps linking for the functions below: each is a thin forward onto the GPU stage of the filter
- * bound to the struct (pfx_loc_spawn_all / apply_vio / apply_range / resample).  They work on the particles in HBM, not
- * on pf->pTag[] (pfx_loc_sync_host fills that on request), and draw their noise from the filter's Philox sub-streams
- * with the filter's current deposit count as epoch.  Same error behaviour as the particleFilterLoc_* entry points.
+ * a program that does keeps linking -- and keeps its meaning -- for the functions below.  Each is a forward onto the GPU
+ * stage of the filter bound to the struct (pfx_loc_spawn_all / apply_vio / apply_range / resample) and, like the
+ * reference's, works on the struct: on entry pf->pTag[] is uploaded if the caller has changed it since the library last
+ * wrote it (a hash of the array is kept beside the binding), on exit pf->pTag[] holds the stage's result and
+ * pf->initialized is whatever the reference leaves there (pfInit_initTagLoc does not set it, pfInit.c:20-25).  Noise
+ * comes from the filter's Philox sub-streams with the filter's current deposit count as epoch.  Same error behaviour
+ * as the particleFilterLoc_* entry points.  A stage call costs two copies of the particle array: these are
+ * compatibility entry points, not the hot path (tests/test_gpu_stage_functions.py).
  *
  * Not exported, and why: the single-particle spawners (pfInit_spawn*Particle*, pfInit.h:25-29)
  * and pfRandom_uniform / normal2 / sphere (pfRandom.h:24-26) are host-side helpers on one AoS particle drawing from the
