@@ -380,6 +380,10 @@ def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, head
     else:
         from slam3d_amd.sharded import ShardedLocFilter
         pf = ShardedLocFilter(n * world, seed=123456789, device=local)
+    exchange = None
+    if hasattr(pf, "uses_library_comm"):
+        exchange = ("in-library RCCL (pfx_loc_shard_deposit_range: one C call per deposit and rank)" if pf.uses_library_comm
+                    else "torch.distributed collectives on views of the library's buffers")
     pf.set_force_branch(force)
     if args.undeferred and world == 1 and not force_sharded:
         pf.set_deferred(False)
@@ -424,6 +428,8 @@ def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, head
         return None, None
     rec = {"value": 2.0 * n * world * K / dt, "ms_per_step": dt / K * 1e3, "particles_per_gpu": n, "steps": K,
            "resample_fraction": float(branches.mean()) if branches.shape[0] else None, "final_position_error_m": err}
+    if exchange:
+        rec["exchange"] = exchange
     # every timed deposit by what its launch did: deposit j follows decision j - 1 (device-side branch log); even j carry
     # the VIO motion, odd j are static
     if full_log.shape[0] >= 2 * K + 1:
@@ -521,7 +527,34 @@ def main():
     if pg != "nccl":
         local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
+    comm_note = None
     if world > 1:
+        # The multi-rank paths have never run on more than one GPU (no such node was available to any round of this
+        # build).  Two guards so that a stall there costs one run, not the series: a watchdog ends a run that has not
+        # finished within BENCH_WATCHDOG_S seconds (rank 0 still prints a JSON line saying so), and leaves a marker on
+        # the node; a later run that finds the marker drives the exchange with torch.distributed collectives instead of
+        # the in-library RCCL path (PFX_SHARD_RCCL=0) and says so in its record.
+        marker = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pfx_bench_library_rccl_stalled")
+        if os.path.exists(marker) and "PFX_SHARD_RCCL" not in os.environ:
+            os.environ["PFX_SHARD_RCCL"] = "0"
+            comm_note = "torch.distributed collectives (an earlier run on this node stalled with the in-library RCCL exchange)"
+        limit = float(os.environ.get("BENCH_WATCHDOG_S", "480"))
+
+        def watchdog():
+            time.sleep(limit)
+            sys.stderr.write(f"bench.py: rank {rank} not finished after {limit:.0f} s: giving up\n")
+            try:
+                if pg == "nccl" and os.environ.get("PFX_SHARD_RCCL", "1") != "0":
+                    open(marker, "w").write("stalled\n")
+                if rank == 0:
+                    emit({"metric": "particle-updates/sec (range update+resample) at N=16M", "value": None, "unit": "particle-updates/s",
+                          "n_gpus": world, "error": f"multi-rank run not finished after {limit:.0f} s (watchdog)",
+                          "comm": comm_note or ("in-library RCCL" if pg == "nccl" else pg)})
+            finally:
+                os._exit(3)
+
+        import threading
+        threading.Thread(target=watchdog, daemon=True).start()
         if pg == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -654,6 +687,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"one filter sharded by particle range over {world} GPUs, "
                                                                        "chunk sums exchanged per deposit, neighbour "
                                                                        "send/recv of migrating offspring per resampling",
+                       "exchange": comm_note or rec.get("exchange"),
                        "force_branch": args.force_branch, "resample_fraction": rec["resample_fraction"],
                        "launch_classes": lc,
                        "deferred_resampling": not args.undeferred or world > 1 or force_sharded,
