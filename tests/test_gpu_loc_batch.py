@@ -31,7 +31,7 @@ def _scene_calls(F, steps, rs):
     return calls
 
 
-@pytest.mark.parametrize("n", [10000, 300000])
+@pytest.mark.parametrize("n", [777, 10000, 65536, 66000, 300000])     # 1 tile; 10 tiles; 64 tiles (last one-wavefront size); 65; two chunks
 def test_batch_equals_single_filters(n):
     from slam3d_amd import particlefilter as pfm
     F, steps = 5, 26
