@@ -34,6 +34,34 @@ __global__ __launch_bounds__(256) void k_read(float* base, long long n, double* 
     if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// AW with what the library's static pass has in front and around: a dependent load of a control word before the tile
+// loads (DEP), 14 KB of LDS per workgroup (LDS), seven workgroups per CU at most (waves_per_eu 7)
+template <bool DEP, bool LDS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_read_like(float* base, long long n, double* out, const int* ctl)
+{
+    __shared__ double red[LDS ? 7 * 256 : 4];
+    const long long tile = blockIdx.x;
+    const int cur = DEP ? ctl[0] : 0;
+    const float ws = DEP ? __int_as_float(ctl[1]) : 1.0001f;
+    float4 v[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) v[q] = *reinterpret_cast<const float4*>(base + (size_t)(q + cur) * n + tile * 1024 + threadIdx.x * 4);
+    float4 w = v[0];
+    double acc = (double)(w.x * v[1].x + w.y * v[2].y + w.z * v[3].z + w.w * v[4].w);
+    w.x *= ws; w.y *= ws; w.z *= ws; w.w *= ws;
+    *reinterpret_cast<float4*>(base + (size_t)cur * n + tile * 1024 + threadIdx.x * 4) = w;
+    if (LDS) {
+        red[threadIdx.x] = acc; red[256 * 6 + threadIdx.x] = acc;
+        __syncthreads();
+        acc = red[threadIdx.x ^ 64] + red[256 * 6 + (threadIdx.x ^ 128)];
+    }
+    acc = wave_sum(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 __global__ __launch_bounds__(256) void k_copy(const float4* a, float4* b)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -62,6 +90,11 @@ int main()
     run("B  tile-interleaved, read only (20 B)", [&](int s) { hipLaunchKernelGGL((k_read<true, false>), dim3(tiles), dim3(256), 0, 0, slab + (size_t)s * n * 5, n, out); }, 20.0 * n);
     run("AW SoA, read 20 B + write w 4 B", [&](int s) { hipLaunchKernelGGL((k_read<false, true>), dim3(tiles), dim3(256), 0, 0, slab + (size_t)s * n * 5, n, out); }, 24.0 * n);
     run("BW tile-interleaved, read 20 B + write w 4 B", [&](int s) { hipLaunchKernelGGL((k_read<true, true>), dim3(tiles), dim3(256), 0, 0, slab + (size_t)s * n * 5, n, out); }, 24.0 * n);
+    int* ctl; hipMalloc(&ctl, 8); { int h[2] = { 0, 0x3f800347 }; hipMemcpy(ctl, h, 8, hipMemcpyHostToDevice); }
+    run("AW + 7 workgroups per CU", [&](int s) { hipLaunchKernelGGL((k_read_like<false, false>), dim3(tiles), dim3(256), 0, 0, slab + (size_t)s * n * 5, n, out, ctl); }, 24.0 * n);
+    run("AW + 7 per CU + dependent control load", [&](int s) { hipLaunchKernelGGL((k_read_like<true, false>), dim3(tiles), dim3(256), 0, 0, slab + (size_t)s * n * 5, n, out, ctl); }, 24.0 * n);
+    run("AW + 7 per CU + 14 KB LDS", [&](int s) { hipLaunchKernelGGL((k_read_like<false, true>), dim3(tiles), dim3(256), 0, 0, slab + (size_t)s * n * 5, n, out, ctl); }, 24.0 * n);
+    run("AW + 7 per CU + dependent load + 14 KB LDS", [&](int s) { hipLaunchKernelGGL((k_read_like<true, true>), dim3(tiles), dim3(256), 0, 0, slab + (size_t)s * n * 5, n, out, ctl); }, 24.0 * n);
     run("C  float4 copy, read 10 B + write 10 B per element", [&](int s) { hipLaunchKernelGGL(k_copy, dim3((unsigned)(n * 5 / 2 / 4 / 256)), dim3(256), 0, 0, reinterpret_cast<const float4*>(slab + (size_t)s * n * 5), reinterpret_cast<float4*>(slab + (size_t)s * n * 5 + n * 5 / 2)); }, 20.0 * n);
     run("A  again", [&](int s) { hipLaunchKernelGGL((k_read<false, false>), dim3(tiles), dim3(256), 0, 0, slab + (size_t)s * n * 5, n, out); }, 20.0 * n);
     return 0;
