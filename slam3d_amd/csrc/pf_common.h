@@ -288,6 +288,37 @@ __device__ __forceinline__ void motion_particle(const RngKey& key, uint64_t inde
     motion_particle_n(nv, mo, smallTurn, x, y, z, th, sn, cs);
 }
 
+// ---------------------------------------------------------------- streaming loads and stores
+// NT = non-temporal form (global_load / global_store ... nt).  Every particle array is read once and written once per
+// pass and is larger than every cache; which accesses gain from the hint is a measured choice per site (PF_NT_* below,
+// pf_loc_kernels.h).
+typedef float pf_v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float* p)
+{
+    if (NT) {
+        const pf_v4f v = __builtin_nontemporal_load(reinterpret_cast<const pf_v4f*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ float ld1(const float* p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float* p, const float4& v)
+{
+    if (NT) {
+        pf_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        __builtin_nontemporal_store(t, reinterpret_cast<pf_v4f*>(p));
+    } else {
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
+
 // ---------------------------------------------------------------- wave / block reductions (wave = 64)
 __device__ __forceinline__ double wave_sum(double v)
 {

@@ -35,6 +35,28 @@ namespace pf {
 #endif
 // The ten particle arrays [ping-pong][w,x,y,z,theta], each padded to a whole tile, lie one after the other in one
 // allocation: base + stride instead of ten pointers keeps 16 scalar registers free in kernels that are short of them.
+// Which accesses of the O(N) passes carry the non-temporal hint (ld4 / st4, pf_common.h); set per site by measurement.
+#ifndef PF_NT_STATIC_LD
+#define PF_NT_STATIC_LD 1
+#endif
+#ifndef PF_NT_STATIC_ST
+#define PF_NT_STATIC_ST 1
+#endif
+#ifndef PF_NT_MOTION_LD
+#define PF_NT_MOTION_LD 0
+#endif
+#ifndef PF_NT_MOTION_ST
+#define PF_NT_MOTION_ST 0
+#endif
+#ifndef PF_NT_RS_W
+#define PF_NT_RS_W 0
+#endif
+#ifndef PF_NT_RS_GATHER
+#define PF_NT_RS_GATHER 0
+#endif
+#ifndef PF_NT_RS_ST
+#define PF_NT_RS_ST 0
+#endif
 struct LocBufs {
     float* slab;
     unsigned long long padded;
@@ -125,11 +147,9 @@ __device__ __forceinline__ void stream_tile_cw(const LocBufs& bufs, int cur, flo
     float* __restrict__ pt = bufs.p(cur, 4);
 
     const long long base = (long long)tile * kTile + (long long)threadIdx.x * kPerThread;
-    const float4 w4 = *reinterpret_cast<const float4*>(pw + base);
-    const float4 x4 = *reinterpret_cast<const float4*>(px + base);
-    const float4 y4 = *reinterpret_cast<const float4*>(py + base);
-    const float4 z4 = *reinterpret_cast<const float4*>(pz + base);
-    const float4 t4 = *reinterpret_cast<const float4*>(pt + base);
+    constexpr bool kLd = MOTION ? PF_NT_MOTION_LD : PF_NT_STATIC_LD, kSt = MOTION ? PF_NT_MOTION_ST : PF_NT_STATIC_ST;
+    const float4 w4 = ld4<kLd>(pw + base), x4 = ld4<kLd>(px + base), y4 = ld4<kLd>(py + base), z4 = ld4<kLd>(pz + base);
+    const float4 t4 = ld4<kLd>(pt + base);
     float w[4] = { w4.x, w4.y, w4.z, w4.w }, x[4] = { x4.x, x4.y, x4.z, x4.w }, y[4] = { y4.x, y4.y, y4.z, y4.w };
     float z[4] = { z4.x, z4.y, z4.z, z4.w }, th[4] = { t4.x, t4.y, t4.z, t4.w };
 
@@ -168,14 +188,14 @@ __device__ __forceinline__ void stream_tile_cw(const LocBufs& bufs, int cur, flo
         acc[6] += wi * z[k];
     }
 
-    *reinterpret_cast<float4*>(pw + base) = make_float4(w[0], w[1], w[2], w[3]);
+    st4<kSt>(pw + base, make_float4(w[0], w[1], w[2], w[3]));
     if (MOTION) {
-        *reinterpret_cast<float4*>(px + base) = make_float4(x[0], x[1], x[2], x[3]);
-        *reinterpret_cast<float4*>(py + base) = make_float4(y[0], y[1], y[2], y[3]);
-        *reinterpret_cast<float4*>(pz + base) = make_float4(z[0], z[1], z[2], z[3]);
-        *reinterpret_cast<float4*>(pt + base) = make_float4(th[0], th[1], th[2], th[3]);
+        st4<kSt>(px + base, make_float4(x[0], x[1], x[2], x[3]));
+        st4<kSt>(py + base, make_float4(y[0], y[1], y[2], y[3]));
+        st4<kSt>(pz + base, make_float4(z[0], z[1], z[2], z[3]));
+        st4<kSt>(pt + base, make_float4(th[0], th[1], th[2], th[3]));
     } else if (thetaChanged) {
-        *reinterpret_cast<float4*>(pt + base) = make_float4(th[0], th[1], th[2], th[3]);
+        st4<kSt>(pt + base, make_float4(th[0], th[1], th[2], th[3]));
     }
 
     block_sum_store<7>(acc, red, tileSums + (size_t)tile * kSumsPerTile);
@@ -1438,10 +1458,10 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
     float4 wFirst = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kAhead > 0) {
         tFirst = P.t0;
-        wFirst = *reinterpret_cast<const float4*>(sw + (size_t)tFirst * kTile + k0);
+        wFirst = ld4<PF_NT_RS_W>(sw + (size_t)tFirst * kTile + k0);
         if (tFirst + 1 < numTiles) {
             tAhead = tFirst + 1;
-            wAhead = *reinterpret_cast<const float4*>(sw + (size_t)tAhead * kTile + k0);
+            wAhead = ld4<PF_NT_RS_W>(sw + (size_t)tAhead * kTile + k0);
         }
 #pragma unroll
         for (int m = 0; m < kAhead1; ++m)
@@ -1490,10 +1510,10 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
                                        : wave_first_true(next + 1, pEnd, [&](int k) { return !(rStart + rStep * pos(k) < tileEnd); });
         }
         const bool lastTile = t == numTiles - 1;
-        const float4 w4 = (t == tFirst) ? wFirst : (t == tAhead) ? wAhead : *reinterpret_cast<const float4*>(sw + (size_t)t * kTile + k0);
+        const float4 w4 = (t == tFirst) ? wFirst : (t == tAhead) ? wAhead : ld4<PF_NT_RS_W>(sw + (size_t)t * kTile + k0);
         if (!lastTile && tAhead != t + 1) {                 // the next source tile is nearly always needed too
             tAhead = t + 1;
-            wAhead = *reinterpret_cast<const float4*>(sw + (size_t)tAhead * kTile + k0);
+            wAhead = ld4<PF_NT_RS_W>(sw + (size_t)tAhead * kTile + k0);
         }
         const int rem = n - t * kTile;
         const int nValid = rem < kTile ? rem : kTile;
@@ -1542,7 +1562,8 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
 #ifdef PF_EXP_NO_GATHER         // timing experiment
             ax[s][m] = (float)j * 1e-7f; ay[s][m] = ax[s][m] + 1.0f; az[s][m] = 1.5f; at[s][m] = ax[s][m];
 #else
-            ax[s][m] = sx[j]; ay[s][m] = sy[j]; az[s][m] = sz[j]; at[s][m] = st[j];
+            ax[s][m] = ld1<PF_NT_RS_GATHER>(sx + j); ay[s][m] = ld1<PF_NT_RS_GATHER>(sy + j);
+            az[s][m] = ld1<PF_NT_RS_GATHER>(sz + j); at[s][m] = ld1<PF_NT_RS_GATHER>(st + j);
 #endif
         }
 
@@ -1613,11 +1634,11 @@ __device__ __forceinline__ void resample_dest_tile(const LocBufs& bufs, const Lo
         if (ow[0] + ox[1] + oy[2] + oz[3] + ot[0] == 12345.678f)
 #endif
         {
-            *reinterpret_cast<float4*>(bufs.p(dst, 0) + e) = make_float4(ow[0], ow[1], ow[2], ow[3]);
-            *reinterpret_cast<float4*>(bufs.p(dst, 1) + e) = make_float4(ox[0], ox[1], ox[2], ox[3]);
-            *reinterpret_cast<float4*>(bufs.p(dst, 2) + e) = make_float4(oy[0], oy[1], oy[2], oy[3]);
-            *reinterpret_cast<float4*>(bufs.p(dst, 3) + e) = make_float4(oz[0], oz[1], oz[2], oz[3]);
-            *reinterpret_cast<float4*>(bufs.p(dst, 4) + e) = make_float4(ot[0], ot[1], ot[2], ot[3]);
+            st4<PF_NT_RS_ST>(bufs.p(dst, 0) + e, make_float4(ow[0], ow[1], ow[2], ow[3]));
+            st4<PF_NT_RS_ST>(bufs.p(dst, 1) + e, make_float4(ox[0], ox[1], ox[2], ox[3]));
+            st4<PF_NT_RS_ST>(bufs.p(dst, 2) + e, make_float4(oy[0], oy[1], oy[2], oy[3]));
+            st4<PF_NT_RS_ST>(bufs.p(dst, 3) + e, make_float4(oz[0], oz[1], oz[2], oz[3]));
+            st4<PF_NT_RS_ST>(bufs.p(dst, 4) + e, make_float4(ot[0], ot[1], ot[2], ot[3]));
         }
         if (RECORD) {
 #pragma unroll

@@ -53,6 +53,14 @@ __host__ __device__ __forceinline__ size_t slam_row_base(const SlamDims& D, int 
 
 struct Row4 { float w[4], x[4], y[4], z[4], th[4]; };
 
+// non-temporal hint on the measured beacon's row loads / stores (k_slam_gate_rows_*), by measurement
+#ifndef PF_SLAM_NT_LD
+#define PF_SLAM_NT_LD 1
+#endif
+#ifndef PF_SLAM_NT_ST
+#define PF_SLAM_NT_ST 1
+#endif
+
 __device__ __forceinline__ void row_load(const float* const (&a)[5], size_t base, int j0, int n, Row4& r)
 {
     // unconditional loads from a clamped index (threads past the row's end read its head and drop it): loads behind a
@@ -75,6 +83,10 @@ __device__ __forceinline__ void row_store1(float* a, size_t base, int j0, int n,
 {
     // rows are padded to a multiple of four floats, so a whole float4 may be written when j0 < n
     if (j0 < n) *reinterpret_cast<float4*>(a + base + j0) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void row_store1_gate(float* a, size_t base, int j0, int n, const float (&v)[4])
+{
+    if (j0 < n) st4<PF_SLAM_NT_ST>(a + base + j0, make_float4(v[0], v[1], v[2], v[3]));
 }
 
 // The scalar part of one small filter's resample-or-normalise decision (pfResample.c:107-121 for the tag
@@ -355,9 +367,9 @@ __device__ __forceinline__ void slam_gate_rows_body(const SlamPtrs& P, const Sla
         const bool in = j0 < n;
         float4 v[5];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(P.bcn[q] + base + jl);
+        for (int q = 0; q < 4; ++q) v[q] = ld4<PF_SLAM_NT_LD>(P.bcn[q] + base + jl);
         v[4] = make_float4(0, 0, 0, 0);
-        if (moving) v[4] = *reinterpret_cast<const float4*>(P.bcn[4] + base + jl);       // uniform over the workgroup
+        if (moving) v[4] = ld4<PF_SLAM_NT_LD>(P.bcn[4] + base + jl);       // uniform over the workgroup
 #pragma unroll
         for (int q = 0; q < 5; ++q)
             if (!in) v[q] = make_float4(0, 0, 0, 0);
@@ -409,12 +421,12 @@ __device__ __forceinline__ void slam_gate_rows_body(const SlamPtrs& P, const Sla
     else
         d = small_filter_update_lazy_theta(r, P.bcn[4] + base, j0, n, L, key, (uint64_t)i * n, (uint64_t)i, st.range, st.stdRange,
                                            tx, ty, tz, rsOut);
-    row_store1(P.bcn[0], base, j0, n, r.w);
+    row_store1_gate(P.bcn[0], base, j0, n, r.w);
     if (moving || d.resample) {
-        row_store1(P.bcn[1], base, j0, n, r.x);
-        row_store1(P.bcn[2], base, j0, n, r.y);
-        row_store1(P.bcn[3], base, j0, n, r.z);
-        row_store1(P.bcn[4], base, j0, n, r.th);
+        row_store1_gate(P.bcn[1], base, j0, n, r.x);
+        row_store1_gate(P.bcn[2], base, j0, n, r.y);
+        row_store1_gate(P.bcn[3], base, j0, n, r.z);
+        row_store1_gate(P.bcn[4], base, j0, n, r.th);
     }
     if (threadIdx.x == 0) {
         rowScale[srow] = d.resample ? 1.0f : d.m;

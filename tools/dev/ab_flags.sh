@@ -25,5 +25,5 @@ for spec in sys.argv[1:]:
     for r in (1, 2):
         d = json.loads([l for l in open(f"gpurun_out/abf_{v}_{r}.json") if l.startswith("{")][-1])
         print(f"{v:14s} run {r}: {d['ms_per_step']:.4f} ms/step  {d['value']/1e9:6.1f} G/s ",
-              {k: round(x["avg_ms"], 4) for k, x in d["kernels"].items()})
+              {k: round(x["avg_ms"], 4) for k, x in d.get("kernels", {}).items()} or d.get("roofline", {}).get("frac"))
 PY
