@@ -57,6 +57,9 @@ struct Row4 { float w[4], x[4], y[4], z[4], th[4]; };
 #ifndef PF_SLAM_NT_LD
 #define PF_SLAM_NT_LD 1
 #endif
+#ifndef PF_SLAM_NT_LDW
+#define PF_SLAM_NT_LDW PF_SLAM_NT_LD
+#endif
 #ifndef PF_SLAM_NT_ST
 #define PF_SLAM_NT_ST 1
 #endif
@@ -366,8 +369,9 @@ __device__ __forceinline__ void slam_gate_rows_body(const SlamPtrs& P, const Sla
         const int jl = j0 < n ? j0 : 0;
         const bool in = j0 < n;
         float4 v[5];
+        v[0] = ld4<PF_SLAM_NT_LDW>(P.bcn[0] + base + jl);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ld4<PF_SLAM_NT_LD>(P.bcn[q] + base + jl);
+        for (int q = 1; q < 4; ++q) v[q] = ld4<PF_SLAM_NT_LD>(P.bcn[q] + base + jl);
         v[4] = make_float4(0, 0, 0, 0);
         if (moving) v[4] = ld4<PF_SLAM_NT_LD>(P.bcn[4] + base + jl);       // uniform over the workgroup
 #pragma unroll
