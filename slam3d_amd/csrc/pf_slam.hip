@@ -101,8 +101,14 @@ struct pfx_slam {
     float* rowTerms = nullptr;      // F * nTag * 6
     int* slotOf = nullptr;          // F
     // per-deposit parameters: ring of pinned host blocks, one device block
-    SlamStep* dSteps = nullptr;
-    Motion* dBcnMo = nullptr;
+    Motion* dBcnMo = nullptr;           // single filter: the beacon motions of the deposit at hand
+    // batches: per-deposit records travel host -> device on a stream of their own, into a ring of device blocks, so that
+    // the copy of deposit k + 1 runs while deposit k's kernels do (in-stream it was 4.6 us of every deposit plus the
+    // hand-over on either side)
+    SlamStep* dStepsRing[kRing] = {};
+    Motion* dBcnMoRing[kRing] = {};
+    hipStream_t copyStream = nullptr;
+    hipEvent_t copyEv[kRing] = {};
     SlamStep* hSteps[kRing] = {};
     Motion* hBcnMo[kRing] = {};
     hipEvent_t ringEv[kRing] = {};
@@ -151,14 +157,17 @@ void free_slam(pfx_slam* pf)
     if (pf->bcnPose) hipFree(pf->bcnPose);
     if (pf->rowTerms) hipFree(pf->rowTerms);
     if (pf->slotOf) hipFree(pf->slotOf);
-    if (pf->dSteps) hipFree(pf->dSteps);
     if (pf->dBcnMo) hipFree(pf->dBcnMo);
     for (int r = 0; r < kRing; ++r) {
+        if (pf->dStepsRing[r]) hipFree(pf->dStepsRing[r]);
+        if (pf->dBcnMoRing[r]) hipFree(pf->dBcnMoRing[r]);
+        if (pf->copyEv[r]) hipEventDestroy(pf->copyEv[r]);
         if (pf->hSteps[r]) hipHostFree(pf->hSteps[r]);
         if (pf->hBcnMo[r]) hipHostFree(pf->hBcnMo[r]);
         if (pf->ringEv[r]) hipEventDestroy(pf->ringEv[r]);
     }
     if (pf->hScratch) hipHostFree(pf->hScratch);
+    if (pf->copyStream) hipStreamDestroy(pf->copyStream);
     if (pf->stream) hipStreamDestroy(pf->stream);
 }
 
@@ -186,9 +195,12 @@ int alloc_slam(pfx_slam* pf)
     PF_HIP_OK(hipMalloc((void**)&pf->bcnPose, F * 6 * sizeof(double)));
     PF_HIP_OK(hipMalloc((void**)&pf->rowTerms, F * D.nTag * 6 * sizeof(float)));
     PF_HIP_OK(hipMalloc((void**)&pf->slotOf, F * sizeof(int)));
-    PF_HIP_OK(hipMalloc((void**)&pf->dSteps, F * sizeof(SlamStep)));
     PF_HIP_OK(hipMalloc((void**)&pf->dBcnMo, F * D.maxBcns * sizeof(Motion)));
+    PF_HIP_OK(hipStreamCreateWithFlags(&pf->copyStream, hipStreamNonBlocking));
     for (int r = 0; r < kRing; ++r) {
+        PF_HIP_OK(hipMalloc((void**)&pf->dStepsRing[r], F * sizeof(SlamStep)));
+        PF_HIP_OK(hipMalloc((void**)&pf->dBcnMoRing[r], F * D.maxBcns * sizeof(Motion)));
+        PF_HIP_OK(hipEventCreateWithFlags(&pf->copyEv[r], hipEventDisableTiming));
         PF_HIP_OK(hipHostMalloc((void**)&pf->hSteps[r], F * sizeof(SlamStep), hipHostMallocDefault));
         PF_HIP_OK(hipHostMalloc((void**)&pf->hBcnMo[r], F * D.maxBcns * sizeof(Motion), hipHostMallocDefault));
         PF_HIP_OK(hipEventCreateWithFlags(&pf->ringEv[r], hipEventDisableTiming));
@@ -248,29 +260,27 @@ int slam_step(pfx_slam* pf, const StepReq* req, int nReq)
         fh.bcnInit[r.target] = true;                        // particleFilter.c:208
     }
     const SlamStep* dMany = nullptr;
+    const Motion* dMo = pf->dBcnMo;
     if (!single) {
-        PF_HIP_OK(hipMemcpyAsync(pf->dSteps, steps, (size_t)F * sizeof(SlamStep), hipMemcpyHostToDevice, pf->stream));
-        dMany = pf->dSteps;
-    }
-    if (anyMoving) {
-        if (single) {
-            // one filter: the motions are few; a blocking copy keeps the pinned block reusable at once
-            PF_HIP_OK(hipMemcpyAsync(pf->dBcnMo, bmo, (size_t)D.maxBcns * sizeof(Motion), hipMemcpyHostToDevice, pf->stream));
-            PF_HIP_OK(hipStreamSynchronize(pf->stream));
-        } else {
-            PF_HIP_OK(hipMemcpyAsync(pf->dBcnMo, bmo, (size_t)F * D.maxBcns * sizeof(Motion), hipMemcpyHostToDevice, pf->stream));
-        }
-    }
-    if (!single) {
-        PF_HIP_OK(hipEventRecord(pf->ringEv[slot], pf->stream));
-        pf->ringUsed[slot] = true;
+        // (the slot's device blocks are free: ringEv[slot], waited for above, was recorded behind the last kernel that read them)
+        PF_HIP_OK(hipMemcpyAsync(pf->dStepsRing[slot], steps, (size_t)F * sizeof(SlamStep), hipMemcpyHostToDevice, pf->copyStream));
+        if (anyMoving)
+            PF_HIP_OK(hipMemcpyAsync(pf->dBcnMoRing[slot], bmo, (size_t)F * D.maxBcns * sizeof(Motion), hipMemcpyHostToDevice, pf->copyStream));
+        PF_HIP_OK(hipEventRecord(pf->copyEv[slot], pf->copyStream));
+        PF_HIP_OK(hipStreamWaitEvent(pf->stream, pf->copyEv[slot], 0));
+        dMany = pf->dStepsRing[slot];
+        dMo = pf->dBcnMoRing[slot];
+    } else if (anyMoving) {
+        // one filter: the motions are few; a blocking copy keeps the pinned block reusable at once
+        PF_HIP_OK(hipMemcpyAsync(pf->dBcnMo, bmo, (size_t)D.maxBcns * sizeof(Motion), hipMemcpyHostToDevice, pf->stream));
+        PF_HIP_OK(hipStreamSynchronize(pf->stream));
     }
     if (anyUpdate) {
         if (anyMoving)
-            hipLaunchKernelGGL(k_slam_gate_rows_moving, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo,
+            hipLaunchKernelGGL(k_slam_gate_rows_moving, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, dMo,
                                pf->rowSum, pf->rowScale, pf->rowFlag, pf->forcedList + F);
         else
-            hipLaunchKernelGGL(k_slam_gate_rows_static, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo,
+            hipLaunchKernelGGL(k_slam_gate_rows_static, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, dMo,
                                pf->rowSum, pf->rowScale, pf->rowFlag, pf->forcedList + F);
         if (check_launch("k_slam_gate_rows")) return -1;
     }
@@ -278,14 +288,18 @@ int slam_step(pfx_slam* pf, const StepReq* req, int nReq)
                        pf->forcedList + F);
     if (check_launch("k_slam_tag")) return -1;
     if (anySpawn || anyMoving) {
-        hipLaunchKernelGGL(k_slam_rows, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, pf->dBcnMo, pf->rowScale,
+        hipLaunchKernelGGL(k_slam_rows, dim3(D.nTag, F), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany, dMo, pf->rowScale,
                            pf->rowFlag);
         if (check_launch("k_slam_rows")) return -1;
     }
     if (anyUpdate) {
         hipLaunchKernelGGL(k_slam_rows_forced, dim3(D.nTag, F < 64 ? F : 64), dim3(kThreads), 0, pf->stream, pf->P, D, one, dMany,
-                           pf->dBcnMo, pf->rowScale, pf->rowFlag, pf->forcedList, pf->forcedList + F);
+                           dMo, pf->rowScale, pf->rowFlag, pf->forcedList, pf->forcedList + F);
         if (check_launch("k_slam_rows_forced")) return -1;
+    }
+    if (!single) {
+        PF_HIP_OK(hipEventRecord(pf->ringEv[slot], pf->stream));
+        pf->ringUsed[slot] = true;
     }
     pf->deposits++;
     return 0;
