@@ -119,3 +119,17 @@ def test_reference_cython_wrapper_builds_against_the_library(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], cwd=work, capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, PYTHONPATH=str(work)))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_pmc_traffic_profile_was_measured_on_these_kernel_sources():
+    """bench.py's roofline.traffic is a constant read from profiles/pmc_traffic.json; the file records the hash of the kernel
+    sources it was measured on (tools/pmc_traffic.py).  A kernel change without a new PMC pass makes bench.py flag the
+    record `traffic_stale`; this keeps the committed state from carrying that flag."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    with open(os.path.join(root, "profiles", "pmc_traffic.json")) as fh:
+        src = json.load(fh).get("_source", {})
+    assert src.get("kernel_sources_sha") == bench.kernel_sources_sha()
