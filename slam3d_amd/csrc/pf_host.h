@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace pf {
 
@@ -27,6 +28,16 @@ void fail(const char* what);
 // particleFilterSeed_set puts back to 0, so that "set the seed, initialise, run" reproduces its sample path however
 // many filters the process has initialised before (the reference reseeds its one global stream, pfRandom.c:51-60).
 uint32_t next_filter_stream();
+
+// The reference-layout entry points (particleFilter.h, pfStages.h) take this lock for the length of a call.  The
+// reference is not thread-safe (one global rand_r state, pfRandom.c:51-52), yet one of its callers drives a filter from
+// two threads without a lock of its own -- mqttlocalize.c: the MQTT callback thread deposits (:294,301) while main polls
+// getTagLoc and reads lastX/Y/Z (:116,129-131).  There a race costs a torn pose; here a deposit and a pose query
+// interleaving on one filter's host-side state machine (deferred resampling, pending launches) would cost the filter.
+// One process-wide lock, recursive because entry points forward to each other; the pfx_* extension stays lock-free
+// (one thread per filter or batch, as include/pfx.h says).
+std::recursive_mutex& api_mutex();
+#define PF_API_LOCK std::lock_guard<std::recursive_mutex> pf_api_lock_(pf::api_mutex())
 
 #define PF_HIP_OK(expr)                                                                         \
     do {                                                                                        \

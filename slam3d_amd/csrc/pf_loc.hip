@@ -41,6 +41,7 @@ void set_error(const char* fmt, ...)
     va_end(ap);
 }
 void clear_error() { last_error_buf()[0] = 0; }
+std::recursive_mutex& api_mutex() { static std::recursive_mutex m; return m; }
 void die(const char* what)
 {
     fprintf(stderr, "libparticlefilter: %s: %s\nlibparticlefilter: there is no CPU fallback; aborting.\n", what, last_error_buf());
@@ -1456,6 +1457,7 @@ void sync_scalars(particleFilterLoc_t* pf, const pfx_loc* h)
 extern "C" void particleFilterSeed_set(unsigned int seed)
 {   // particleFilter.c:26-30.  The reference's next draw after this call is the first of the stream of `seed`
     // whatever happened before; here the sub-stream counter starts over for the same reason.
+    PF_API_LOCK;
     PF_SEED = seed;
     PF_SEED_SET = 1;
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1464,6 +1466,7 @@ extern "C" void particleFilterSeed_set(unsigned int seed)
 
 extern "C" void particleFilterLoc_init(particleFilterLoc_t* pf)
 {   // particleFilter.c:32-46 + pfRandom.c:56-60 (seed from the clock unless one was set)
+    PF_API_LOCK;
     if (!PF_SEED_SET) PF_SEED = (unsigned int)time(nullptr);
     const uint32_t sid = next_filter_stream();
     pfx_loc* h = bound(pf);
@@ -1480,6 +1483,7 @@ extern "C" void particleFilterLoc_init(particleFilterLoc_t* pf)
 
 extern "C" void particleFilterLoc_depositVio(particleFilterLoc_t* pf, double t, float x, float y, float z, float dist)
 {
+    PF_API_LOCK;
     pfx_loc* h = must_be_bound(pf, "particleFilterLoc_depositVio");
     if (!h) return;
     pfx_loc_deposit_vio(h, t, x, y, z, dist);
@@ -1488,6 +1492,7 @@ extern "C" void particleFilterLoc_depositVio(particleFilterLoc_t* pf, double t, 
 
 extern "C" void particleFilterLoc_depositRange(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
 {
+    PF_API_LOCK;
     pfx_loc* h = must_be_bound(pf, "particleFilterLoc_depositRange");
     if (!h) return;
     if (pfx_loc_deposit_range(h, bx, by, bz, range, stdRange)) { fail("particleFilterLoc_depositRange"); return; }
@@ -1496,6 +1501,7 @@ extern "C" void particleFilterLoc_depositRange(particleFilterLoc_t* pf, float bx
 
 extern "C" void particleFilterLoc_depositRssi(particleFilterLoc_t* pf, float bx, float by, float bz, int rssi)
 {
+    PF_API_LOCK;
     pfx_loc* h = must_be_bound(pf, "particleFilterLoc_depositRssi");
     if (!h) return;
     if (pfx_loc_deposit_rssi(h, bx, by, bz, rssi)) { fail("particleFilterLoc_depositRssi"); return; }
@@ -1504,6 +1510,7 @@ extern "C" void particleFilterLoc_depositRssi(particleFilterLoc_t* pf, float bx,
 
 extern "C" uint8_t particleFilterLoc_getTagLoc(const particleFilterLoc_t* pf, double* t, float* x, float* y, float* z, float* theta)
 {
+    PF_API_LOCK;
     pfx_loc* h = must_be_bound(pf, "particleFilterLoc_getTagLoc");
     if (!h) return 0;
     const int rc = pfx_loc_get_tag_loc(h, t, x, y, z, theta);
@@ -1544,12 +1551,14 @@ void stage_exit(particleFilterLoc_t* pf, pfx_loc* h, const char* fn)
 
 extern "C" void pfRandom_init(void)
 {   // pfRandom.c:56-60
+    PF_API_LOCK;
     if (!PF_SEED_SET) PF_SEED = (unsigned int)time(nullptr);
 }
 
 extern "C" void pfInit_initTagLoc(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
 {   // pfInit.c:20-25.  The caller sets pf->initialized afterwards, as particleFilter.c:188-189 does: the library picks the
     // flag up from the struct at the next call (must_be_bound).
+    PF_API_LOCK;
     pfx_loc* h = must_be_bound(pf, "pfInit_initTagLoc");
     if (!h) return;
     if (pfx_loc_spawn_all(h, bx, by, bz, range, stdRange)) { fail("pfInit_initTagLoc"); return; }
@@ -1558,6 +1567,7 @@ extern "C" void pfInit_initTagLoc(particleFilterLoc_t* pf, float bx, float by, f
 
 extern "C" void pfMeasurement_applyVioLoc(particleFilterLoc_t* pf, float dt, float dx, float dy, float dz, float ddist)
 {   // pfMeasurement.c:24-49
+    PF_API_LOCK;
     pfx_loc* h = stage_enter(pf, "pfMeasurement_applyVioLoc");
     if (!h) return;
     if (pfx_loc_apply_vio(h, dt, dx, dy, dz, ddist)) { fail("pfMeasurement_applyVioLoc"); return; }
@@ -1566,6 +1576,7 @@ extern "C" void pfMeasurement_applyVioLoc(particleFilterLoc_t* pf, float dt, flo
 
 extern "C" void pfMeasurement_applyRangeLoc(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
 {   // pfMeasurement.c:108-125
+    PF_API_LOCK;
     pfx_loc* h = stage_enter(pf, "pfMeasurement_applyRangeLoc");
     if (!h) return;
     if (pfx_loc_apply_range(h, bx, by, bz, range, stdRange)) { fail("pfMeasurement_applyRangeLoc"); return; }
@@ -1574,6 +1585,7 @@ extern "C" void pfMeasurement_applyRangeLoc(particleFilterLoc_t* pf, float bx, f
 
 extern "C" void pfResample_resampleLoc(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)
 {   // pfResample.c:30-84
+    PF_API_LOCK;
     pfx_loc* h = stage_enter(pf, "pfResample_resampleLoc");
     if (!h) return;
     if (pfx_loc_resample(h, bx, by, bz, range, stdRange)) { fail("pfResample_resampleLoc"); return; }
@@ -1584,6 +1596,7 @@ extern "C" pfx_loc* pfx_loc_of(const particleFilterLoc_t* pf) { return bound(pf)
 
 extern "C" int pfx_loc_sync_host(particleFilterLoc_t* pf)
 {   // fill the caller-visible AoS array from HBM (first PF_N_TAG_LOC particles if the filter holds more)
+    PF_API_LOCK;
     clear_error();
     pfx_loc* h = bound(pf);
     if (!h) { set_error("pfx_loc_sync_host: struct is not bound"); return -2; }
@@ -1604,6 +1617,7 @@ extern "C" int pfx_loc_sync_host(particleFilterLoc_t* pf)
 
 extern "C" void pfx_loc_release(particleFilterLoc_t* pf)
 {
+    PF_API_LOCK;
     pfx_loc* h = bound(pf);
     if (!h) return;
     pfx_loc_destroy(h);

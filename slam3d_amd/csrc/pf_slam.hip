@@ -124,6 +124,10 @@ struct pfx_slam {
     // whose binding record shows another count holds a copy of an earlier state (see "POD copies" below)
     unsigned long long legacyOps = 0;
     unsigned long long bcnOps[kSlamMaxBcns] = {};
+    // ... and the deposit (value of legacyOps) that last listed each slot: when all slots are taken, a bcn_t the filter has
+    // not met before takes over the slot that has gone unlisted the longest (callers that free() their beacons never say
+    // so: slam3d-jni.c:34-37)
+    unsigned long long slotSeen[kSlamMaxBcns] = {};
 };
 
 static std::mutex g_smu;
@@ -832,7 +836,7 @@ int slot_of(pfx_slam* h, bcn_t* b, const char* fn)
     BcnStash* s = stash_of(b);
     const bool mine = s->magic == kBcnMagic && s->self == (uint64_t)(uintptr_t)b && s->owner == h && s->process == g_slamProcess &&
                       s->slot >= 0 && s->slot < h->fl[0].numBcns;
-    if (mine && s->ops == h->bcnOps[s->slot]) return (int)s->slot;
+    if (mine && s->ops == h->bcnOps[s->slot]) { h->slotSeen[s->slot] = h->legacyOps + 1; return (int)s->slot; }
     // Not this filter's beacon as it last saw it.  A struct that carries a record of this library (a copy, a checkpoint
     // read back, bytes copied back over the live struct) must hold its particles to be continued; one without a record
     // (filled by the reference library, or reset with particleFilterSlam_addBcn) is taken at its word.
@@ -848,11 +852,28 @@ int slot_of(pfx_slam* h, bcn_t* b, const char* fn)
         slot = (int)s->slot;                // rolled back in place: its rows are replaced below
     } else if (it != h->legacySlots.end()) {
         slot = it->second;                  // reset with particleFilterSlam_addBcn: same struct, same slot, spawned afresh
-    } else {
+    } else if (h->fl[0].numBcns < h->D.maxBcns) {
         slot = pfx_slam_add_bcn(h, 0);
         if (slot < 0) return -1;
         h->legacySlots[(uintptr_t)b] = slot;
+    } else {
+        // Every slot is taken.  The reference API has no call that gives a beacon up -- its callers just free() the struct
+        // (slam3d-jni.c:34-37) -- so the slot that has gone unlisted in allBcns the longest, and is not part of the call at
+        // hand, is taken to be such a beacon and handed on.  Should its struct come back after all, its binding record no
+        // longer matches (bcnOps) and it is continued from its own pBcn[][] or refused, like any other out-of-date copy.
+        slot = -1;
+        for (int c = 0; c < h->D.maxBcns; ++c)
+            if (h->slotSeen[c] <= h->legacyOps && (slot < 0 || h->slotSeen[c] < h->slotSeen[slot])) slot = c;
+        if (slot < 0) {
+            set_error("%s: more than %d distinct beacons in one call", fn, h->D.maxBcns);
+            return -1;
+        }
+        for (auto it2 = h->legacySlots.begin(); it2 != h->legacySlots.end();)
+            it2 = it2->second == slot ? h->legacySlots.erase(it2) : std::next(it2);
+        h->legacySlots[(uintptr_t)b] = slot;
+        h->fl[0].bcnVio[slot] = VioAcc();
     }
+    h->slotSeen[slot] = h->legacyOps + 1;       // part of the call at hand (legacy_deposit bumps legacyOps at its end)
     h->fl[0].bcnInit[slot] = false;
     if (b->initialized) {
         // A beacon that says it holds particles but has no rows on the device (a struct filled by the reference
@@ -935,6 +956,7 @@ extern "C" void particleFilterSlam_init(particleFilterSlam_t* pf)
 {   // particleFilter.c:48-63 + pfRandom.c:56-60 (seed from the clock unless one was set).  Filters initialised after one
     // particleFilterSeed_set share Philox key word 1 = 0 for their tag particles and slot + 1 for their beacons, so the
     // n-th of them gets its own key word 0: the seed plus n golden-ratio steps (n = 0: the seed itself).
+    PF_API_LOCK;
     if (!PF_SEED_SET) PF_SEED = (unsigned int)time(nullptr);
     const uint32_t seed = PF_SEED + 0x9E3779B9u * next_filter_stream();
     pfx_slam* h = bound(pf);
@@ -961,6 +983,7 @@ extern "C" void particleFilterSlam_init(particleFilterSlam_t* pf)
 
 extern "C" void particleFilterSlam_addBcn(bcn_t* bcn)
 {   // particleFilter.c:65-68: only clears `initialized`; the beacon meets its filter at the first deposit
+    PF_API_LOCK;
     bcn->initialized = 0;
     BcnStash* s = stash_of(bcn);
     s->magic = 0; s->self = 0; s->owner = nullptr; s->slot = -1;
@@ -968,6 +991,7 @@ extern "C" void particleFilterSlam_addBcn(bcn_t* bcn)
 
 extern "C" void particleFilterSlam_depositTagVio(particleFilterSlam_t* pf, double t, float x, float y, float z, float dist)
 {   // particleFilter.c:106-140: host bookkeeping in the caller's struct
+    PF_API_LOCK;
     VioAcc v = vio_load(pf);
     vio_deposit(v, t, x, y, z, dist);
     vio_store(pf, v);
@@ -975,6 +999,7 @@ extern "C" void particleFilterSlam_depositTagVio(particleFilterSlam_t* pf, doubl
 
 extern "C" void particleFilterSlam_depositBcnVio(bcn_t* bcn, double t, float x, float y, float z, float dist)
 {   // particleFilter.c:142-176
+    PF_API_LOCK;
     VioAcc v = vio_load(bcn);
     vio_deposit(v, t, x, y, z, dist);
     vio_store(bcn, v);
@@ -983,17 +1008,20 @@ extern "C" void particleFilterSlam_depositBcnVio(bcn_t* bcn, double t, float x, 
 extern "C" void particleFilterSlam_depositRange(particleFilterSlam_t* pf, bcn_t* bcn, float range, float stdRange, bcn_t** allBcns,
                                                 int numBcns)
 {
+    PF_API_LOCK;
     legacy_deposit(pf, bcn, range, stdRange, allBcns, numBcns, "particleFilterSlam_depositRange");
 }
 
 extern "C" void particleFilterSlam_depositRssi(particleFilterSlam_t* pf, bcn_t* bcn, int rssi, bcn_t** allBcns, int numBcns)
 {   // particleFilter.c:228-246
+    PF_API_LOCK;
     (void)rssi;
     legacy_deposit(pf, bcn, 1.5f, 0.5f, allBcns, numBcns, "particleFilterSlam_depositRssi");
 }
 
 extern "C" uint8_t particleFilterSlam_getTagLoc(const particleFilterSlam_t* pf, double* t, float* x, float* y, float* z, float* theta)
 {
+    PF_API_LOCK;
     if (!pf->initialized) return 0;
     pfx_slam* h = must_be_bound(pf, "particleFilterSlam_getTagLoc");
     if (!h) return 0;
@@ -1006,6 +1034,7 @@ extern "C" uint8_t particleFilterSlam_getTagLoc(const particleFilterSlam_t* pf, 
 extern "C" uint8_t particleFilterSlam_getBcnLoc(const particleFilterSlam_t* pf, const bcn_t* bcn, double* t, float* x, float* y,
                                                 float* z, float* theta)
 {
+    PF_API_LOCK;
     if (!bcn->initialized) return 0;
     pfx_slam* h = must_be_bound(pf, "particleFilterSlam_getBcnLoc");
     if (!h) return 0;
@@ -1029,6 +1058,7 @@ extern "C" int pfx_slam_slot_of(const particleFilterSlam_t* pf, const bcn_t* bcn
 
 extern "C" int pfx_slam_sync_host(particleFilterSlam_t* pf, bcn_t* bcn)
 {   // fill pf->pTag[] and (if given) bcn->pBcn[][] (AoS) from HBM; needs the reference's compile-time counts
+    PF_API_LOCK;
     clear_error();
     pfx_slam* h = bound(pf);
     if (!h) { set_error("pfx_slam_sync_host: struct is not bound"); return -2; }
@@ -1064,6 +1094,7 @@ extern "C" int pfx_slam_sync_host(particleFilterSlam_t* pf, bcn_t* bcn)
 
 extern "C" void pfx_slam_release(particleFilterSlam_t* pf)
 {
+    PF_API_LOCK;
     pfx_slam* h = bound(pf);
     if (!h) return;
     pfx_slam_destroy(h);

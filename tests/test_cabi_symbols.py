@@ -82,6 +82,27 @@ def test_reference_callers_link_unchanged(tmp_path, src):
     assert "particleFilter" in out      # resolved from the shared library, not compiled in
 
 
+def test_front_end_pattern_program_links(tmp_path):
+    """tests/c/front_end_patterns.c (the call patterns of the reference's JNI shim and MQTT front end; run on
+    the GPU by tests/test_gpu_front_ends.py) is plain C99 over the two public headers and links against the library."""
+    from slam3d_amd import _lib
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "fe"
+    subprocess.check_call(["gcc", "-O1", "-std=gnu99", "-Wall", "-Werror", "-pthread", "-o", str(exe),
+                           os.path.join(root, "tests", "c", "front_end_patterns.c"), "-I", INC, "-L", libdir, "-lparticlefilter", "-lm",
+                           f"-Wl,-rpath,{libdir}"])
+    und = subprocess.check_output(["nm", "-u", str(exe)]).decode()
+    for fn in ("particleFilterSlam_init", "particleFilterSlam_addBcn", "particleFilterSlam_depositTagVio", "particleFilterSlam_depositBcnVio",
+               "particleFilterSlam_depositRange", "particleFilterSlam_depositRssi", "particleFilterSlam_getTagLoc",
+               "particleFilterSlam_getBcnLoc", "particleFilterLoc_init", "particleFilterLoc_depositVio", "particleFilterLoc_depositRange",
+               "particleFilterLoc_getTagLoc"):
+        assert fn in und, fn
+    # the copy the GPU tests run is the one the Makefile built from the same source
+    built = os.path.join(root, "slam3d_amd", "bin", "front_end_patterns")
+    assert os.path.exists(built) and os.path.getmtime(built) >= os.path.getmtime(os.path.join(root, "tests", "c", "front_end_patterns.c"))
+
+
 @pytest.mark.skipif(not os.path.isfile("/root/reference/particlefilter/cython/particlefilter_wrapper.pyx"),
                     reason="the reference tree only exists in the build container")
 def test_reference_cython_wrapper_builds_against_the_library(tmp_path):
