@@ -7,7 +7,12 @@
  *
  * Conventions: plain C ABI, host pointers unless a parameter is named d_* (device pointer);
  * functions returning int give 0 on success and a negative code on failure, after which
- * pfx_last_error() describes it.  A filter is not thread-safe (neither is the reference's:
+ * pfx_last_error() describes it.  Argument errors (-2, -3) are found before anything changes.  A
+ * failure of the GPU side (-1: a launch or copy refused by the runtime) leaves pfx_loc_deposit_range /
+ * _rssi and the reference-layout entry points without effect (VIO accumulator and deposit count as
+ * before); a batch (pfx_loc_batch_*, pfx_slam_*_batch) has by then consumed the VIO deltas of the
+ * filters of that deposit and is to be destroyed, as is any filter after a failed collective of the
+ * sharded path.  A filter is not thread-safe through this header (neither is the reference's:
  * one global rand_r stream); all work of one filter is ordered on its own HIP stream and is
  * asynchronous to the host except the calls that return data.
  */
