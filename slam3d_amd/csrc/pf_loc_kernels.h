@@ -1686,8 +1686,11 @@ __global__ __launch_bounds__(kThreads) void k_loc_resample_dest(LocBufs bufs, Lo
 // destination tiles per workgroup, PF_DEPOSIT_TILES = 2, needs 85 registers and lost: 0.196), and arithmetic that
 // depends on nothing but the counter -- the unit normals of the thread's first two offspring -- drawn while the wave
 // waits for the source weights and for the ancestors (PF_NOISE_AHEAD1/2: 0.182 -> 0.163; a third offspring spills).
+#ifndef PF_DEPOSIT_WAVES
+#define PF_DEPOSIT_WAVES 7
+#endif
 template <bool MOTION>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_loc_deposit(LocBufs bufs, const LocCtl* __restrict__ ctl,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(PF_DEPOSIT_WAVES, PF_DEPOSIT_WAVES))) void k_loc_deposit(LocBufs bufs, const LocCtl* __restrict__ ctl,
                                                          double* __restrict__ tileSums,
                                                          const double* __restrict__ chunkBase,
                                                          const double* __restrict__ tileIncl, int numTiles, int n,
