@@ -28,6 +28,10 @@ void fail(const char* what);
 // particleFilterSeed_set puts back to 0, so that "set the seed, initialise, run" reproduces its sample path however
 // many filters the process has initialised before (the reference reseeds its one global stream, pfRandom.c:51-60).
 uint32_t next_filter_stream();
+// pfRandom.c:56-60: a filter initialised before any particleFilterSeed_set is seeded from the clock.  PF_HIP_SEED (an
+// unsigned decimal) stands in for the clock, so that programs which never set a seed -- csvlocalize.c, csvslam.c, the JNI
+// shim -- can be run reproducibly without a source change.
+unsigned int unset_seed();
 
 // The reference-layout entry points (particleFilter.h, pfStages.h) take this lock for the length of a call.  The
 // reference is not thread-safe (one global rand_r state, pfRandom.c:51-52), yet one of its callers drives a filter from

@@ -42,6 +42,12 @@ void set_error(const char* fmt, ...)
 }
 void clear_error() { last_error_buf()[0] = 0; }
 std::recursive_mutex& api_mutex() { static std::recursive_mutex m; return m; }
+unsigned int unset_seed()
+{
+    const char* e = getenv("PF_HIP_SEED");
+    if (e && *e) return (unsigned int)strtoul(e, nullptr, 10);
+    return (unsigned int)time(nullptr);
+}
 void die(const char* what)
 {
     fprintf(stderr, "libparticlefilter: %s: %s\nlibparticlefilter: there is no CPU fallback; aborting.\n", what, last_error_buf());
@@ -1467,7 +1473,7 @@ extern "C" void particleFilterSeed_set(unsigned int seed)
 extern "C" void particleFilterLoc_init(particleFilterLoc_t* pf)
 {   // particleFilter.c:32-46 + pfRandom.c:56-60 (seed from the clock unless one was set)
     PF_API_LOCK;
-    if (!PF_SEED_SET) PF_SEED = (unsigned int)time(nullptr);
+    if (!PF_SEED_SET) PF_SEED = unset_seed();
     const uint32_t sid = next_filter_stream();
     pfx_loc* h = bound(pf);
     if (h) {
@@ -1552,7 +1558,7 @@ void stage_exit(particleFilterLoc_t* pf, pfx_loc* h, const char* fn)
 extern "C" void pfRandom_init(void)
 {   // pfRandom.c:56-60
     PF_API_LOCK;
-    if (!PF_SEED_SET) PF_SEED = (unsigned int)time(nullptr);
+    if (!PF_SEED_SET) PF_SEED = unset_seed();
 }
 
 extern "C" void pfInit_initTagLoc(particleFilterLoc_t* pf, float bx, float by, float bz, float range, float stdRange)

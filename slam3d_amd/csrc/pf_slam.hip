@@ -957,7 +957,7 @@ extern "C" void particleFilterSlam_init(particleFilterSlam_t* pf)
     // particleFilterSeed_set share Philox key word 1 = 0 for their tag particles and slot + 1 for their beacons, so the
     // n-th of them gets its own key word 0: the seed plus n golden-ratio steps (n = 0: the seed itself).
     PF_API_LOCK;
-    if (!PF_SEED_SET) PF_SEED = (unsigned int)time(nullptr);
+    if (!PF_SEED_SET) PF_SEED = unset_seed();
     const uint32_t seed = PF_SEED + 0x9E3779B9u * next_filter_stream();
     pfx_slam* h = bound(pf);
     if (h) {
