@@ -70,7 +70,10 @@ def gc_paused():
     full (generation-2) collection takes 40-60 ms; the wrappers allocate a few ctypes / numpy objects per call, so one
     such collection can land inside a 15-50 ms timed loop and double its time (measured: config 5, 120 steps, 0.231 ms
     per step with the collector paused, 0.50-0.76 ms when one full collection fell into the loop; the same loop from
-    C++, tools/dev/slam_loop.cpp, 0.226 ms).  That is the interpreter's housekeeping, not the path under measurement."""
+    C++, tools/dev/slam_loop.cpp, 0.226 ms).  That is the interpreter's housekeeping, not the path under measurement.
+    The pause begins BEFORE the warm-up steps: the collection it starts with leaves the GPU idle for those 40-60 ms, and a
+    timed loop that starts right behind it runs its first milliseconds at the clocks of an idle part (a 20-step run came
+    out 11 % slower that way, resampling side 0.181 ms against 0.158)."""
     gc.collect()
     was = gc.isenabled()
     gc.disable()
@@ -340,12 +343,12 @@ def measure_slam(F, B, K, W, world, rank, local, dist, torch, with_cpu=False, ce
         batch.sync()
         torch.cuda.synchronize()
 
-    for k in range(B):          # first range of every beacon (spawn), untimed
-        one(k)
-    for k in range(B, B + W):
-        one(k)
-    barrier()
     with gc_paused():
+        for k in range(B):          # first range of every beacon (spawn), untimed
+            one(k)
+        for k in range(B, B + W):
+            one(k)
+        barrier()
         t0 = time.perf_counter()
         for k in range(B + W, B + W + K):
             one(k)
@@ -416,19 +419,18 @@ def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, head
     # init (spawn) + pre-roll + warm-up, untimed
     pf.depositVio(999.9, float(truth[0, 0]), float(truth[0, 1]), float(truth[0, 2]), 0.0)
     pf.depositRange(float(bx[0, 0]), float(bx[0, 1]), float(bx[0, 2]), float(rng[0, 0]), 0.1)
-    for k in range(PRE_ROLL + W):
-        step(pf, k, bx, truth, rng, ranges_only)
-    barrier()
-
     events = headline and not args.no_kernel_events
-    if events:
-        # the O(N) kernels only: the two tiny prefix / decision launches of every deposit are not reported, and timing
-        # them too costs ~12 us of GPU time per step
-        pf.profile_only("stream", "stream_static", "resample", "deposit", "deposit_static")
-        pf.profile_stride(args.event_stride)     # every event_stride-th launch of a class carries events (~3 us each)
-        pf.profile_begin(4 * K * 4 + 16)
-    barrier()
     with gc_paused():
+        for k in range(PRE_ROLL + W):
+            step(pf, k, bx, truth, rng, ranges_only)
+        barrier()
+        if events:
+            # the O(N) kernels only: the two tiny prefix / decision launches of every deposit are not reported, and
+            # timing them too costs ~12 us of GPU time per step
+            pf.profile_only("stream", "stream_static", "resample", "deposit", "deposit_static")
+            pf.profile_stride(args.event_stride)     # every event_stride-th launch of a class carries events (~3 us each)
+            pf.profile_begin(4 * K * 4 + 16)
+        barrier()
         t0 = time.perf_counter()
         for k in range(PRE_ROLL + W, PRE_ROLL + W + K):
             step(pf, k, bx, truth, rng, ranges_only)
@@ -774,11 +776,11 @@ def measure_loc_batch(pfm, torch, local, F, n, K, W=20):
     batch.deposit_vio(np.full(F, 999.9), truth[off, 0], truth[off, 1], truth[off, 2], np.zeros(F, dtype=np.float32))
     batch.deposit_range(bx[off % 8, 0], bx[off % 8, 1], bx[off % 8, 2], rng[off, 0], np.full(F, 0.1, dtype=np.float32))
     pre = min(PRE_ROLL, 100)
-    for k in range(pre + W):
-        one(k)
-    d0, r0 = batch.branch_counts()          # (synchronises)
-    torch.cuda.synchronize()
     with gc_paused():
+        for k in range(pre + W):
+            one(k)
+        d0, r0 = batch.branch_counts()          # (synchronises)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(pre + W, pre + W + K):
             one(k)
