@@ -333,9 +333,17 @@ def measure_slam(F, B, K, W, world, rank, local, dist, torch, with_cpu=False, ce
     truth, dfun = _slam_inputs(B, K + W + B + census_steps + 1)
     ones = np.ones(F, dtype=np.float32)
 
+    # per-step arguments in arrays that live as long as the batch (a caller that feeds a batch keeps such arrays anyway)
+    a_t, a_x, a_y, a_z = np.zeros(F), ones.copy(), ones.copy(), ones.copy()
+    a_slot, a_r, a_sd = np.zeros(F, dtype=np.int32), ones.copy(), ones * np.float32(0.1)
+
     def one(k):
-        batch.deposit_tag_vio_batch(np.full(F, 1000.0 + 0.1 * k), ones * truth[k, 0], ones * truth[k, 1], ones * truth[k, 2])
-        batch.deposit_range_batch(np.full(F, k % B, dtype=np.int32), ones * dfun(k), ones * np.float32(0.1))
+        a_t[:] = 1000.0 + 0.1 * k
+        a_x[:] = truth[k, 0]; a_y[:] = truth[k, 1]; a_z[:] = truth[k, 2]
+        batch.deposit_tag_vio_batch(a_t, a_x, a_y, a_z)
+        a_slot[:] = k % B
+        a_r[:] = dfun(k)
+        batch.deposit_range_batch(a_slot, a_r, a_sd)
 
     def barrier():
         if world > 1:
