@@ -439,21 +439,28 @@ def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, head
             pf.profile_stride(args.event_stride)     # every event_stride-th launch of a class carries events (~3 us each)
             pf.profile_begin(4 * K * 4 + 16)
         barrier()
+        sent0 = int(getattr(pf, "exchanged_particles", 0))
         t0 = time.perf_counter()
         for k in range(PRE_ROLL + W, PRE_ROLL + W + K):
             step(pf, k, bx, truth, rng, ranges_only)
         barrier()
         dt = time.perf_counter() - t0
+        sent = int(getattr(pf, "exchanged_particles", 0)) - sent0       # offspring this rank shipped to other shards
 
     kinds, ms = pf.profile_records() if events else (np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float32))
     full_log = pf.branch_log()[0]       # rank 0's log; a sharded filter takes the same decision on every rank
     branches = full_log[-2 * K:]
     pose = pf.getTagLoc()
     err = float(np.linalg.norm(np.array(pose[2:5], dtype=np.float64) - truth[PRE_ROLL + W + K - 1]))
+    sent_max = sent_sum = sent
     if world > 1:
         t = torch.tensor([dt], device="cuda" if pg == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        c = torch.tensor([sent, sent], device="cuda" if pg == "nccl" else "cpu", dtype=torch.int64)
+        dist.all_reduce(c[0:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(c[1:2], op=dist.ReduceOp.SUM)
+        sent_max, sent_sum = int(c[0].item()), int(c[1].item())
     del pf
     if rank != 0:
         return None, None
@@ -461,6 +468,12 @@ def measure_loc(pfm, torch, dist, world, rank, local, n, K, W, force, args, head
            "resample_fraction": float(branches.mean()) if branches.shape[0] else None, "final_position_error_m": err}
     if exchange:
         rec["exchange"] = exchange
+        # what the neighbour exchange of the resampling deposits moved in the timed loop (16 B per offspring that changes
+        # shard): in this scene the 5 % respawn lands on global indices [0, numSpawn) -- shard 0 -- with weight 1 against
+        # ~0.1-0.5 elsewhere, every shard boundary of the offspring shifts, and ~3 % of ALL particles cross each boundary per
+        # resampling (tools/dev/diag_migration.py): at 64 M that is ~30 MB per link and resampling
+        rec["offspring_shipped_per_step"] = {"all_ranks": sent_sum / K, "busiest_rank": sent_max / K,
+                                             "bytes_per_step_busiest_rank": 16.0 * sent_max / K}
     # every timed deposit by what its launch did: deposit j follows decision j - 1 (device-side branch log); even j carry
     # the VIO motion, odd j are static
     if full_log.shape[0] >= 2 * K + 1:

@@ -1668,8 +1668,11 @@ const RcclApi* rccl()
 {
     std::lock_guard<std::mutex> lk(g_rcclMu);
     if (g_rccl.so) return &g_rccl;
-    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // PFX_RCCL_LIB: another library with RCCL's entry points -- the tests' shared-memory loopback (tests/c/rccl_loopback.cpp),
+    // which lets several ranks share one GPU; RCCL itself refuses that
+    const char* over = getenv("PFX_RCCL_LIB");
+    void* so = (over && *over) ? dlopen(over, RTLD_NOW | RTLD_LOCAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!so && !(over && *over)) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!so) { set_error("RCCL is not available: %s", dlerror()); return nullptr; }
     RcclApi a;
     a.so = so;

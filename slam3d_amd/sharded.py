@@ -272,7 +272,10 @@ class ShardedLocFilter:
         self.stage_capacity = cap
         self._pg_is_nccl = dist.get_backend(group) == "nccl"
         self._comm = False
-        if backend_factory is None and self._pg_is_nccl and os.environ.get("PFX_SHARD_RCCL", "1") != "0":
+        # PFX_SHARD_RCCL: "0" never, "force" also under a process group that is not nccl (the tests: gloo for the hand-shake,
+        # PFX_RCCL_LIB = the shared-memory loopback for the exchange, several ranks on one GPU), default: when the group is nccl
+        mode = os.environ.get("PFX_SHARD_RCCL", "1")
+        if backend_factory is None and mode != "0" and (self._pg_is_nccl or mode == "force"):
             self._comm = self._init_library_comm()
         self.initialized = False
         self._outstanding = False               # a decision has been launched and not acted on yet
@@ -293,7 +296,8 @@ class ShardedLocFilter:
                 ok = 0
             ident[0] = bytes(buf)
         dist.broadcast_object_list(ident, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-        flag = torch.tensor([ok], device=f"cuda:{self.shard.device}", dtype=torch.int32)
+        fdev = f"cuda:{self.shard.device}" if self._pg_is_nccl else "cpu"
+        flag = torch.tensor([ok], device=fdev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         if int(flag.item()) == 0:
             return False
@@ -304,7 +308,7 @@ class ShardedLocFilter:
             import sys
             print(f"slam3d_amd.sharded: in-library RCCL not used on rank {self.rank}: {e}", file=sys.stderr)
             ok = 0
-        flag = torch.tensor([ok], device=f"cuda:{self.shard.device}", dtype=torch.int32)
+        flag = torch.tensor([ok], device=fdev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return int(flag.item()) == 1
 

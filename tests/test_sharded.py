@@ -34,13 +34,13 @@ def _free_port():
     return p
 
 
-def _run(world, backend, n, steps, force=-1, timeout=300, pose_every=1, concentrate=0):
+def _run(world, backend, n, steps, force=-1, timeout=300, pose_every=1, concentrate=0, extra_env=None):
     out = tempfile.mkdtemp(prefix="shard_")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), WORKER,
            "--backend", backend, "--pg", "gloo", "--particles", str(n), "--steps", str(steps), "--force", str(force), "--pose-every", str(pose_every),
            "--concentrate", str(concentrate), "--out", out]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", **(extra_env or {}))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return [np.load(os.path.join(out, f"rank{k}.npz")) for k in range(world)]
@@ -143,6 +143,36 @@ def test_sharded_gpu_ranks_match_single_gpu(world, pose_every):
     poses = W.drive(g, W.events(steps), lambda f: branches.append(int(f.last_stats()["branch"])), pose_every)
     ref = g.download()
     shards = _run(world, "gpu", n, steps, pose_every=pose_every)
+    _compare(shards, ref, poses, np.array(branches), n, tol=1e-6)
+    assert max(int(s["moved"][-1]) for s in shards) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,pose_every,force", [(2, 1, -1), (2, 4, -1), (3, 3, -1), (3, 2, 1), (4, 5, -1)])
+def test_sharded_gpu_ranks_library_exchange_over_loopback(world, pose_every, force):
+    """The IN-LIBRARY exchange (pfx_loc_shard_deposit_range / _settle / _get_tag_loc: one C call per deposit and rank, the
+    path `bench.py --gpus N` takes on an nccl process group) with more than one rank.  RCCL refuses two ranks on one
+    device and the box has one, so the ten RCCL entry points the library binds at run time come from
+    slam3d_amd/lib/librccl_loopback.so instead (tests/c/rccl_loopback.cpp: the same calls over shared memory, host-staged;
+    PFX_RCCL_LIB), the unique id travels over gloo as it would over nccl, and PFX_SHARD_RCCL=force switches the path on
+    under a gloo group.  What this covers that nothing else does: comm_ship's grouped sends and receives with real peers
+    (buffers, offsets, counts, who enters the group and who does not), the all-gather of the chunk-sum rows and the
+    all-reduce of the pose sums across ranks -- against the single-GPU filter, weights and z bit for bit.  force = 1:
+    every deposit resamples and ships."""
+    from slam3d_amd import particlefilter as pfm
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import sharded_worker as W
+    loop = os.path.join(ROOT, "slam3d_amd", "lib", "librccl_loopback.so")
+    assert os.path.exists(loop), "slam3d_amd/lib/librccl_loopback.so is missing: make -C slam3d_amd/csrc"
+    n, steps = 300007, 14
+    g = pfm.DeviceParticleFilterLoc(n, seed=123456789)
+    g.set_force_branch(force)
+    branches = []
+    poses = W.drive(g, W.events(steps), lambda f: branches.append(int(f.last_stats()["branch"])), pose_every)
+    ref = g.download()
+    shards = _run(world, "gpu", n, steps, force=force, pose_every=pose_every,
+                  extra_env={"PFX_SHARD_RCCL": "force", "PFX_RCCL_LIB": loop})
+    assert all(int(s["library_comm"]) == 1 for s in shards), "the in-library exchange was not the one running"
     _compare(shards, ref, poses, np.array(branches), n, tol=1e-6)
     assert max(int(s["moved"][-1]) for s in shards) > 0
 
