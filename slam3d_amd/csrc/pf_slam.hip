@@ -271,7 +271,10 @@ int slam_step(pfx_slam* pf, const StepReq* req, int nReq)
         if (anyMoving)
             PF_HIP_OK(hipMemcpyAsync(pf->dBcnMoRing[slot], bmo, (size_t)F * D.maxBcns * sizeof(Motion), hipMemcpyHostToDevice, pf->copyStream));
         PF_HIP_OK(hipEventRecord(pf->copyEv[slot], pf->copyStream));
-        PF_HIP_OK(hipStreamWaitEvent(pf->stream, pf->copyEv[slot], 0));
+        // The HOST waits for the copy (~10 us; the GPU is a few deposits behind and does not notice), not the stream: a
+        // cross-queue wait in front of the row kernel cost 10.5 us of idle GPU per deposit (kernel trace, config 5) --
+        // as much as the in-stream blit this ring replaced; same-box A/B 0.2555 -> 0.2517 ms per step.
+        PF_HIP_OK(hipEventSynchronize(pf->copyEv[slot]));
         dMany = pf->dStepsRing[slot];
         dMo = pf->dBcnMoRing[slot];
     } else if (anyMoving) {
