@@ -229,7 +229,11 @@ int slam_step(pfx_slam* pf, const StepReq* req, int nReq)
     if (!single) {
         slot = pf->ringPos;
         pf->ringPos = (pf->ringPos + 1) % kRing;
-        if (pf->ringUsed[slot]) PF_HIP_OK(hipEventSynchronize(pf->ringEv[slot]));
+        // One event per HALF of the ring (an event record between two deposits idles the GPU for ~5 us, kernel trace):
+        // ringEv[h] is recorded behind the last deposit of half h; a half is entered again only once the event of its
+        // previous round has fired, i.e. every kernel that read its four blocks has finished.
+        constexpr int kHalf = kRing / 2;
+        if (slot % kHalf == 0 && pf->ringUsed[slot / kHalf]) PF_HIP_OK(hipEventSynchronize(pf->ringEv[slot / kHalf]));
         steps = pf->hSteps[slot];
         for (int f = 0; f < F; ++f) steps[f].mode = 0;
     }
@@ -305,8 +309,11 @@ int slam_step(pfx_slam* pf, const StepReq* req, int nReq)
         if (check_launch("k_slam_rows_forced")) return -1;
     }
     if (!single) {
-        PF_HIP_OK(hipEventRecord(pf->ringEv[slot], pf->stream));
-        pf->ringUsed[slot] = true;
+        constexpr int kHalf = kRing / 2;
+        if (slot % kHalf == kHalf - 1) {
+            PF_HIP_OK(hipEventRecord(pf->ringEv[slot / kHalf], pf->stream));
+            pf->ringUsed[slot / kHalf] = true;
+        }
     }
     pf->deposits++;
     return 0;
