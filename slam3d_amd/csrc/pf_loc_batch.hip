@@ -21,7 +21,9 @@
 using namespace pf;
 
 namespace {
-constexpr int kRing = 4;        // pinned staging buffers for the step records
+constexpr int kRing = 8;        // pinned staging buffers for the step records
+constexpr int kHalf = kRing / 2;    // one "free again" event per half of the ring: an event record between two kernels idles
+                                    // the GPU for ~6 us (kernel trace: the gap between k_locb_prepare and k_locb_deposit)
 }
 
 struct pfx_loc_batch {
@@ -35,8 +37,8 @@ struct pfx_loc_batch {
     BatchStep* dSteps = nullptr;            // [F] on the device: the filters' step records (k_locb_prepare keeps them)
     BatchIn* hSteps[kRing] = {};            // pinned, device-mapped: what the host sends per operation
     BatchIn* hStepsDev[kRing] = {};         // ... as the device addresses them
-    hipEvent_t hFree[kRing] = {};           // recorded behind the k_locb_prepare that reads hSteps[i]
-    bool hUsed[kRing] = {};
+    hipEvent_t hFree[2] = {};               // recorded behind the k_locb_prepare that reads the last buffer of a half
+    bool hUsed[2] = {};
     int ring = 0;
     LocCtl* hostCtl = nullptr;              // pinned, [F]
     int force = -1;
@@ -63,10 +65,10 @@ void free_batch(pfx_loc_batch* b)
     if (B.chunkBase) hipFree(B.chunkBase);
     if (B.plan) hipFree(B.plan);
     if (b->dSteps) hipFree(b->dSteps);
-    for (int i = 0; i < kRing; ++i) {
+    for (int i = 0; i < kRing; ++i)
         if (b->hSteps[i]) hipHostFree(b->hSteps[i]);
+    for (int i = 0; i < 2; ++i)
         if (b->hFree[i]) hipEventDestroy(b->hFree[i]);
-    }
     if (b->hostCtl) hipHostFree(b->hostCtl);
     if (b->stream) hipStreamDestroy(b->stream);
 }
@@ -99,8 +101,8 @@ int alloc_batch(pfx_loc_batch* b)
         PF_HIP_OK(hipHostMalloc((void**)&b->hSteps[i], F * sizeof(BatchIn), hipHostMallocMapped));
         memset(b->hSteps[i], 0, F * sizeof(BatchIn));
         PF_HIP_OK(hipHostGetDevicePointer((void**)&b->hStepsDev[i], b->hSteps[i], 0));
-        PF_HIP_OK(hipEventCreateWithFlags(&b->hFree[i], hipEventDisableTiming));
     }
+    for (int i = 0; i < 2; ++i) PF_HIP_OK(hipEventCreateWithFlags(&b->hFree[i], hipEventDisableTiming));
     PF_HIP_OK(hipHostMalloc((void**)&b->hostCtl, F * sizeof(LocCtl), hipHostMallocDefault));
     // every control block as pfx_loc_create leaves it: buffer 0, nothing pending, factor 1
     std::vector<LocCtl> init(F);
@@ -115,7 +117,8 @@ int alloc_batch(pfx_loc_batch* b)
 BatchIn* stage_begin(pfx_loc_batch* b)
 {
     const int i = b->ring;
-    if (b->hUsed[i]) hipEventSynchronize(b->hFree[i]);
+    // entering a half of the ring: every k_locb_prepare that read its buffers in the previous round has finished
+    if (i % kHalf == 0 && b->hUsed[i / kHalf]) hipEventSynchronize(b->hFree[i / kHalf]);
     return b->hSteps[i];
 }
 // k_locb_prepare on the buffer just filled: the records reach the device, per-deposit scalars and gate bounds are derived
@@ -124,8 +127,10 @@ int stage_send(pfx_loc_batch* b)
     const int i = b->ring;
     hipLaunchKernelGGL(k_locb_prepare, dim3((b->F + 63) / 64), dim3(64), 0, b->stream, b->hStepsDev[i], b->dSteps, b->B.ctl, b->F);
     if (check_launch("k_locb_prepare")) return -1;
-    PF_HIP_OK(hipEventRecord(b->hFree[i], b->stream));
-    b->hUsed[i] = true;
+    if (i % kHalf == kHalf - 1) {
+        PF_HIP_OK(hipEventRecord(b->hFree[i / kHalf], b->stream));
+        b->hUsed[i / kHalf] = true;
+    }
     b->ring = (i + 1) % kRing;
     return 0;
 }
