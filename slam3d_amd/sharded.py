@@ -250,7 +250,7 @@ class ShardedLocFilter:
     """particleFilterLoc of n_total particles over all ranks of a torch.distributed process group."""
 
     def __init__(self, n_total: int, seed: int = 0, device: int = 0, group=None, backend_factory=None,
-                 stage_slack: float = 1.0):
+                 stage_slack: Optional[float] = None):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -264,7 +264,15 @@ class ShardedLocFilter:
         n_local = self.T[self.rank + 1] - self.T[self.rank]
         if n_local < 1:
             raise ValueError("fewer particles than ranks")
-        cap = int(n_local * stage_slack) + 1024
+        # Staging area for the offspring a shard produces for others, in units of its own size.  Default: the worst case, one
+        # shard producing every offspring of a resampling (all the weight inside its index range) -- world x its own size,
+        # 32 B per record for the send and the landing half together.  Not a corner case: right after the spawn the cloud
+        # collapses onto a fraction of the range shell, and in bench.py's scene one shard of four shipped 1.08 x its own
+        # size in one of the first resamplings (found by the four-rank rehearsal over the loopback transport; with the
+        # former default of 1.0 that run stopped with "shard imbalance beyond the configured slack").
+        if stage_slack is None:
+            stage_slack = float(self.world)
+        cap = min(int(n_local * stage_slack) + 1024, (1 << 31) - 1024)        # (record indices are 32-bit on the device)
         if backend_factory is None:
             self.shard = GpuShard(n_local, self.n_total, self.T[self.rank], self.rank, self.world, seed, device, cap)
         else:
