@@ -27,7 +27,7 @@
 
 namespace {
 
-constexpr int kMaxRanks = 4;
+constexpr int kMaxRanks = 8;
 constexpr size_t kSlotBytes = 1 << 20;              // per rank, collectives (chunk-sum rows: <= 64 KB; pose sums: 48 B)
 constexpr size_t kBoxBytes = (size_t)1 << 30;             // per ordered pair, point-to-point (16 B per migrating offspring); the
                                                     // segment is sparse: only what a test really sends is ever touched

@@ -148,7 +148,7 @@ def test_sharded_gpu_ranks_match_single_gpu(world, pose_every):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,pose_every,force", [(2, 1, -1), (2, 4, -1), (3, 3, -1), (3, 2, 1), (4, 5, -1)])
+@pytest.mark.parametrize("world,pose_every,force", [(2, 1, -1), (2, 4, -1), (3, 3, -1), (3, 2, 1), (4, 5, -1), (8, 3, -1)])
 def test_sharded_gpu_ranks_library_exchange_over_loopback(world, pose_every, force):
     """The IN-LIBRARY exchange (pfx_loc_shard_deposit_range / _settle / _get_tag_loc: one C call per deposit and rank, the
     path `bench.py --gpus N` takes on an nccl process group) with more than one rank.  RCCL refuses two ranks on one
