@@ -70,8 +70,11 @@ def main():
     ap.add_argument("--concentrate", type=int, default=0,
                     help="after the spawn, leave weight only on global particles [n/8 + 10, n/4 - 10): one shard of eight then "
                          "feeds all the others (oracle backend)")
+    ap.add_argument("--stage-slack", type=float, default=1.0, help="staging area in units of the shard; 0 = the library's default (world)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
+    if a.stage_slack == 0:
+        a.stage_slack = None
 
     import torch
     import torch.distributed as dist
@@ -86,7 +89,7 @@ def main():
         factory = OracleShard
     dev = int(os.environ.get("LOCAL_RANK", "0")) if a.pg == "nccl" else 0
     # staging area = slack x the shard's own size: a shard that feeds all eight needs room for seven shards' worth
-    pf = ShardedLocFilter(a.n, seed=a.seed, device=dev, backend_factory=factory, stage_slack=8.0 if a.concentrate else 1.0)
+    pf = ShardedLocFilter(a.n, seed=a.seed, device=dev, backend_factory=factory, stage_slack=8.0 if a.concentrate else a.stage_slack)
     pf.set_force_branch(a.force)
     branches, moved = [], []
 
