@@ -222,3 +222,41 @@ def test_slam_deposit_without_resampling_equals_the_compiled_reference(ref, rng_
     for k in range(1, 5):
         assert np.array_equal(got_tag[k], exp_tag[k]), k
     assert np.abs(got_tag[0] / exp_tag[0] - 1.0).max() < 1e-6
+
+
+def test_resampling_indices_equal_the_compiled_reference(ref):
+    """north_star: "when fed identical uniform draws and weights, resampling indices must be bit-exact" -- against the
+    reference's own loop (pfResample.c:41-50, 67-72), run by the compiled reference.  The draw: the reference takes rStart
+    from its stream first thing in branch A, so the same seed set twice gives the value once through pfRandom_uniform and
+    once inside resampleLoc.  The indices: the particles sit 10 m apart on the x axis and the jitter has sigma 0.1
+    (pfInit.c:68-79), so every offspring names its ancestor.  The GPU side is pfx_resample_indices_f32: the reference's
+    float32 expression on the reference's float32 CDF."""
+    from slam3d_amd import particlefilter as pfm
+    r = np.random.default_rng(21)
+    w = np.full(N, 2.0 ** -10, dtype=np.float32)
+    heavy = r.choice(N, size=N * 3 // 10, replace=False)
+    w[heavy] = (r.integers(512, 2048, size=heavy.shape[0]) / 1024.0).astype(np.float32)
+    x = (10.0 * np.arange(N)).astype(np.float32)
+    a = [w, x, np.zeros(N, dtype=np.float32), np.zeros(N, dtype=np.float32), np.zeros(N, dtype=np.float32)]
+    ref.pfRandom_uniform.restype = C.c_float
+    ref.particleFilterSeed_set(4711)
+    u = np.float32(ref.pfRandom_uniform())
+    ref.particleFilterSeed_set(4711)
+    s = _Loc()
+    _fill(s, a)
+    ref.pfResample_resampleLoc(C.byref(s), 0.0, 0.0, 0.0, 10.0, 0.1)       # range >= 4: no respawn
+    out = _read(s)
+    assert np.all(out[0] == 1.0), "the reference took branch B: the case is not the one meant"
+    anc_ref = np.rint(out[1].astype(np.float64) / 10.0).astype(np.int64)
+    assert np.abs(out[1] - 10.0 * anc_ref).max() < 1.0
+    # the reference's CDF and scalars, in its arithmetic (pfResample.c:41-50, 67-68)
+    cdf = np.empty(N, dtype=np.float32)
+    acc = np.float32(0.0)
+    for i in range(N):
+        acc = np.float32(acc + w[i])
+        cdf[i] = acc
+    r_step = np.float32(np.float32(np.float32(1.0) / np.float32(N)) * acc)         # rStep = invN * s, invN = 1.0f / N (:53,67)
+    r_start = np.float32(u * r_step)
+    idx = pfm.resample_indices_f32(cdf, float(r_start), float(r_step))
+    assert idx.shape == (N,) and np.array_equal(idx.astype(np.int64), anc_ref)
+    assert np.unique(anc_ref).shape[0] < N * 0.4            # it was a real selection
